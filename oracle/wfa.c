@@ -1,0 +1,680 @@
+/* ORACLE (test infrastructure) -- gap-affine / gap-affine-2p wavefront
+ * alignment, end-to-end, exact (no heuristic), restating WFA2-lib as driven by
+ * the reference through lib_wfa2 (src/wfa.rs:41-75:
+ * AffineWavefronts::with_penalties_affine2p_and_memory_mode(.., Ultralow),
+ * AlignmentScope::Alignment, AlignmentSpan::End2End, HeuristicStrategy::None;
+ * .align/.score/.cigar usage src/seqrush_bidirected.rs:218-236).
+ *
+ * WFA2-lib / lib_wfa2 @819b82cd are NOT in the reference tree, so
+ * this file restates the published algorithm:
+ *   - wavefront recurrences, diagonal k = h - v, offset = h (text position),
+ *     pattern = query (v), text = target (h);
+ *   - backtrace: among predecessor candidates take the maximum offset, ties
+ *     resolved by the piggy-backed type tag, priority high->low:
+ *     mismatch > D2-ext > D2-open > D1-ext > D1-open > I2-ext > I2-open >
+ *     I1-ext > I1-open   (SURVEY Appendix A);
+ *   - MemoryMode::Ultralow = biWFA: forward and reverse score-only aligners
+ *     advance alternately, overlap detection per component, recursion on the
+ *     breakpoint with begin/end component constraints, fall back to plain WFA
+ *     with backtrace when the remaining score <= 250 or both lengths <= 100.
+ * Known answers that pin it: tests/test_wfa2_cigar_debug.rs:4-30
+ * (ATCGATCG vs ATCGATCGATCG -> MMMMMMMMIIII), tests/test_cigar_validity.rs.
+ * Co-optimal tie-breaking and biWFA breakpoint choice vs the real WFA2-lib:
+ * PARITY UNPINNED.  The HIP kernels implement exactly the rules written here.
+ *
+ * Cell semantics used here and on the GPU: every stored offset is either
+ * WF_NULL or an in-bounds furthest-reaching point (0 <= h <= tlen,
+ * 0 <= v <= plen); out-of-bounds candidates are nulled for all components.
+ */
+#include "sr_oracle.h"
+#include <limits.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+
+#define WF_NULL (-(1 << 28))
+#define IMAX(a, b) ((a) > (b) ? (a) : (b))
+#define IMIN(a, b) ((a) < (b) ? (a) : (b))
+
+/* backtrace type tags (priority = numeric value) */
+enum { BT_I1_OPEN = 1, BT_I1_EXT = 2, BT_I2_OPEN = 3, BT_I2_EXT = 4,
+       BT_D1_OPEN = 5, BT_D1_EXT = 6, BT_D2_OPEN = 7, BT_D2_EXT = 8,
+       BT_MISMS = 9 };
+
+typedef struct {
+    const uint8_t *p, *t;
+    int plen, tlen;
+    int rev;
+} view_t;
+
+static inline int base_eq(const view_t *w, int v, int h) {
+    if (w->rev) return w->p[w->plen - 1 - v] == w->t[w->tlen - 1 - h];
+    return w->p[v] == w->t[h];
+}
+
+typedef struct {
+    int score;      /* score held by this slot, -1 = none */
+    int lo, hi;     /* lo > hi : empty level */
+    int off0;       /* index = k + off0 */
+    int32_t *c[5];
+} level_t;
+
+typedef struct {
+    view_t w;
+    int x, o1, e1, o2, e2, two;
+    int scope;
+    int modular;
+    level_t *lv;
+    int nlv;        /* modular: scope ; full: allocated count */
+    int cap, shift; /* modular storage */
+    uint64_t cells;
+} wfa_t;
+
+static _Thread_local uint64_t g_last_cells;
+uint64_t sro_wfa_last_cells(void) { return g_last_cells; }
+
+static int pen_scope(const sro_penalties *pen) {
+    int s = IMAX(pen->mismatch, pen->gap_open1 + pen->gap_ext1);
+    if (pen->gap_open2 >= 0) s = IMAX(s, pen->gap_open2 + pen->gap_ext2);
+    return s + 1;
+}
+
+static void wfa_init(wfa_t *a, const view_t *w, const sro_penalties *pen,
+                     int modular) {
+    memset(a, 0, sizeof(*a));
+    a->w = *w;
+    a->x = pen->mismatch; a->o1 = pen->gap_open1; a->e1 = pen->gap_ext1;
+    a->two = pen->gap_open2 >= 0;
+    a->o2 = a->two ? pen->gap_open2 : 0;
+    a->e2 = a->two ? pen->gap_ext2 : 0;
+    a->scope = pen_scope(pen);
+    a->modular = modular;
+    if (modular) {
+        a->nlv = a->scope;
+        a->cap = w->plen + w->tlen + 3;
+        a->shift = w->plen + 1;
+        a->lv = (level_t *)calloc((size_t)a->nlv, sizeof(level_t));
+        for (int i = 0; i < a->nlv; i++) {
+            a->lv[i].score = -1;
+            a->lv[i].lo = 1; a->lv[i].hi = 0;
+            a->lv[i].off0 = a->shift;
+            for (int j = 0; j < 5; j++)
+                a->lv[i].c[j] = (int32_t *)malloc(sizeof(int32_t) * (size_t)a->cap);
+        }
+    } else {
+        a->nlv = 0;
+        a->lv = NULL;
+    }
+}
+
+static void wfa_free(wfa_t *a) {
+    int n = a->nlv;
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < 5; j++) free(a->lv[i].c[j]);
+    free(a->lv);
+    a->lv = NULL;
+}
+
+/* slot that will hold score s (allocating in full mode) */
+static level_t *wfa_slot(wfa_t *a, int s) {
+    if (a->modular) return &a->lv[s % a->scope];
+    if (s >= a->nlv) {
+        int n = a->nlv ? a->nlv : 64;
+        while (n <= s) n *= 2;
+        a->lv = (level_t *)realloc(a->lv, sizeof(level_t) * (size_t)n);
+        for (int i = a->nlv; i < n; i++) {
+            memset(&a->lv[i], 0, sizeof(level_t));
+            a->lv[i].score = -1; a->lv[i].lo = 1; a->lv[i].hi = 0;
+        }
+        a->nlv = n;
+    }
+    return &a->lv[s];
+}
+
+/* level holding score s, or NULL when absent/empty */
+static const level_t *wfa_level(const wfa_t *a, int s) {
+    if (s < 0) return NULL;
+    const level_t *L;
+    if (a->modular) L = &a->lv[s % a->scope];
+    else { if (s >= a->nlv) return NULL; L = &a->lv[s]; }
+    if (L->score != s || L->lo > L->hi) return NULL;
+    return L;
+}
+
+static inline int32_t lv_get(const level_t *L, int comp, int k) {
+    if (!L || k < L->lo || k > L->hi || !L->c[comp]) return WF_NULL;
+    return L->c[comp][k + L->off0];
+}
+
+static void lv_prepare(wfa_t *a, level_t *L, int s, int lo, int hi) {
+    L->score = s; L->lo = lo; L->hi = hi;
+    if (!a->modular) {
+        L->off0 = -lo;
+        size_t n = (size_t)(hi >= lo ? hi - lo + 1 : 1);
+        for (int j = 0; j < 5; j++) {
+            free(L->c[j]);
+            L->c[j] = (int32_t *)malloc(sizeof(int32_t) * n);
+        }
+    }
+}
+
+static inline int32_t bnd(int32_t c, uint32_t lim) {
+    return ((uint32_t)c > lim) ? WF_NULL : c;
+}
+
+static inline int32_t wf_extend(const view_t *w, int k, int32_t off) {
+    int v = off - k, h = off;
+    while (v < w->plen && h < w->tlen && base_eq(w, v, h)) { v++; h++; }
+    return h;
+}
+
+/* level 0: begin component at (k=0, offset 0) */
+static void wfa_level0(wfa_t *a, int begin) {
+    level_t *L = wfa_slot(a, 0);
+    lv_prepare(a, L, 0, 0, 0);
+    for (int j = 0; j < 5; j++) L->c[j][0 + L->off0] = WF_NULL;
+    int32_t off = 0;
+    if (begin == SRO_M) off = wf_extend(&a->w, 0, 0);
+    L->c[begin][0 + L->off0] = off;
+    a->cells += 1;
+}
+
+/* one score step: compute + bound + extend (WFA2 wavefront_compute_affine2p
+ * + wavefront_extend_end2end) */
+static void wfa_step(wfa_t *a, int s) {
+    const level_t *Lx = wfa_level(a, s - a->x);
+    const level_t *Lo1 = wfa_level(a, s - a->o1 - a->e1);
+    const level_t *Le1 = wfa_level(a, s - a->e1);
+    const level_t *Lo2 = a->two ? wfa_level(a, s - a->o2 - a->e2) : NULL;
+    const level_t *Le2 = a->two ? wfa_level(a, s - a->e2) : NULL;
+    int lo = INT_MAX, hi = INT_MIN;
+    if (Lx) { lo = IMIN(lo, Lx->lo); hi = IMAX(hi, Lx->hi); }
+    if (Lo1) { lo = IMIN(lo, Lo1->lo - 1); hi = IMAX(hi, Lo1->hi + 1); }
+    if (Le1) { lo = IMIN(lo, Le1->lo - 1); hi = IMAX(hi, Le1->hi + 1); }
+    if (Lo2) { lo = IMIN(lo, Lo2->lo - 1); hi = IMAX(hi, Lo2->hi + 1); }
+    if (Le2) { lo = IMIN(lo, Le2->lo - 1); hi = IMAX(hi, Le2->hi + 1); }
+    level_t *L = wfa_slot(a, s);
+    if (lo > hi) { L->score = s; L->lo = 1; L->hi = 0; return; }
+    const int plen = a->w.plen, tlen = a->w.tlen;
+    lo = IMAX(lo, -plen); hi = IMIN(hi, tlen);
+    if (lo > hi) { L->score = s; L->lo = 1; L->hi = 0; return; }
+    /* in modular mode the output slot may alias a source level only when
+     * that source is older than scope, which never happens */
+    lv_prepare(a, L, s, lo, hi);
+    int any_lo = INT_MAX, any_hi = INT_MIN;
+    for (int k = lo; k <= hi; k++) {
+        const uint32_t lim = (uint32_t)IMIN(tlen, plen + k);
+        /* every candidate is bounded on its own, so M is null iff all
+         * components are null on this diagonal */
+        int32_t i1 = bnd(IMAX(lv_get(Lo1, SRO_M, k - 1), lv_get(Le1, SRO_I1, k - 1)) + 1, lim);
+        int32_t d1 = bnd(IMAX(lv_get(Lo1, SRO_M, k + 1), lv_get(Le1, SRO_D1, k + 1)), lim);
+        int32_t i2 = WF_NULL, d2 = WF_NULL;
+        if (a->two) {
+            i2 = bnd(IMAX(lv_get(Lo2, SRO_M, k - 1), lv_get(Le2, SRO_I2, k - 1)) + 1, lim);
+            d2 = bnd(IMAX(lv_get(Lo2, SRO_M, k + 1), lv_get(Le2, SRO_D2, k + 1)), lim);
+        }
+        int32_t m = bnd(lv_get(Lx, SRO_M, k) + 1, lim);
+        m = IMAX(m, IMAX(IMAX(i1, i2), IMAX(d1, d2)));
+        if (m < 0) m = WF_NULL;
+        if (m >= 0) m = wf_extend(&a->w, k, m);
+        const int idx = k + L->off0;
+        L->c[SRO_M][idx] = m; L->c[SRO_I1][idx] = i1; L->c[SRO_I2][idx] = i2;
+        L->c[SRO_D1][idx] = d1; L->c[SRO_D2][idx] = d2;
+        if (m >= 0) { any_lo = IMIN(any_lo, k); any_hi = IMAX(any_hi, k); }
+    }
+    a->cells += (uint64_t)(hi - lo + 1);
+    /* M is the max of all components, so a level is empty iff M is null
+     * everywhere; trimming null ends changes no value */
+    if (any_lo > any_hi) { L->lo = 1; L->hi = 0; }
+    else if (a->modular) { L->lo = any_lo; L->hi = any_hi; }
+    else {
+        /* full mode keeps storage base at the original lo */
+        L->off0 = -lo; L->lo = any_lo; L->hi = any_hi;
+    }
+}
+
+/* ---------------- CIGAR buffer ---------------- */
+typedef struct { uint8_t *b; int n, cap; } cig_t;
+static void cig_push(cig_t *c, uint8_t op, int count) {
+    if (count <= 0) return;
+    if (c->n + count > c->cap) {
+        int nc = c->cap ? c->cap : 256;
+        while (nc < c->n + count) nc *= 2;
+        c->b = (uint8_t *)realloc(c->b, (size_t)nc);
+        c->cap = nc;
+    }
+    memset(c->b + c->n, op, (size_t)count);
+    c->n += count;
+}
+
+/* ---------------- plain WFA with backtrace ---------------- */
+static int bt_best(int32_t *best_off, int *best_type, int32_t off, int type) {
+    if (off < 0) return 0;
+    if (off > *best_off || (off == *best_off && type > *best_type)) {
+        *best_off = off; *best_type = type;
+    }
+    return 1;
+}
+
+/* Full-memory WFA on view w between components cb -> ce.  Appends the raw
+ * CIGAR (forward order) to out.  Returns score or <0 on failure. */
+static int wfa_full(const view_t *w, const sro_penalties *pen, int cb, int ce,
+                    cig_t *out, uint64_t *cells) {
+    wfa_t a;
+    wfa_init(&a, w, pen, 0);
+    const int plen = w->plen, tlen = w->tlen;
+    const int k_end = tlen - plen;
+    /* hard bound: delete everything + insert everything (+ slack) */
+    long smax = (long)a.o1 + (long)a.e1 * plen + (long)a.o1 + (long)a.e1 * tlen
+                + 4L * (a.two ? IMAX(a.o1, a.o2) : a.o1) + 16;
+    wfa_level0(&a, cb);
+    int s = 0, found = 0;
+    for (;;) {
+        const level_t *L = wfa_level(&a, s);
+        if (L && lv_get(L, ce, k_end) >= tlen) { found = 1; break; }
+        if (s > smax) break;
+        s++;
+        wfa_step(&a, s);
+    }
+    if (!found) { wfa_free(&a); return -1; }
+    const int score = s;
+    /* backtrace (WFA2 wavefront_backtrace_affine semantics) */
+    cig_t r = {0, 0, 0};   /* reversed */
+    int k = k_end, comp = ce;
+    int32_t off = tlen;
+    int ok = 1;
+    for (;;) {
+        if (comp == SRO_M) {
+            if (s == 0) {
+                /* only reachable when cb == M: initial stroke of matches */
+                if (cb != SRO_M || k != 0) { ok = 0; break; }
+                cig_push(&r, 'M', off);
+                off = 0;
+                break;
+            }
+            int32_t bo = WF_NULL; int bty = 0;
+            const level_t *Lx = wfa_level(&a, s - a.x);
+            const level_t *Lo1 = wfa_level(&a, s - a.o1 - a.e1);
+            const level_t *Le1 = wfa_level(&a, s - a.e1);
+            const uint32_t lim = (uint32_t)IMIN(tlen, plen + k);
+            bt_best(&bo, &bty, bnd(lv_get(Lx, SRO_M, k) + 1, lim), BT_MISMS);
+            bt_best(&bo, &bty, bnd(lv_get(Lo1, SRO_M, k - 1) + 1, lim), BT_I1_OPEN);
+            bt_best(&bo, &bty, bnd(lv_get(Le1, SRO_I1, k - 1) + 1, lim), BT_I1_EXT);
+            bt_best(&bo, &bty, bnd(lv_get(Lo1, SRO_M, k + 1), lim), BT_D1_OPEN);
+            bt_best(&bo, &bty, bnd(lv_get(Le1, SRO_D1, k + 1), lim), BT_D1_EXT);
+            if (a.two) {
+                const level_t *Lo2 = wfa_level(&a, s - a.o2 - a.e2);
+                const level_t *Le2 = wfa_level(&a, s - a.e2);
+                bt_best(&bo, &bty, bnd(lv_get(Lo2, SRO_M, k - 1) + 1, lim), BT_I2_OPEN);
+                bt_best(&bo, &bty, bnd(lv_get(Le2, SRO_I2, k - 1) + 1, lim), BT_I2_EXT);
+                bt_best(&bo, &bty, bnd(lv_get(Lo2, SRO_M, k + 1), lim), BT_D2_OPEN);
+                bt_best(&bo, &bty, bnd(lv_get(Le2, SRO_D2, k + 1), lim), BT_D2_EXT);
+            }
+            if (bty == 0 || bo > off) { ok = 0; break; }
+            cig_push(&r, 'M', off - bo);
+            off = bo;
+            switch (bty) {
+            case BT_MISMS: cig_push(&r, 'X', 1); off -= 1; s -= a.x; break;
+            case BT_I1_OPEN: cig_push(&r, 'I', 1); off -= 1; k -= 1; s -= a.o1 + a.e1; break;
+            case BT_I1_EXT: cig_push(&r, 'I', 1); off -= 1; k -= 1; s -= a.e1; comp = SRO_I1; break;
+            case BT_I2_OPEN: cig_push(&r, 'I', 1); off -= 1; k -= 1; s -= a.o2 + a.e2; break;
+            case BT_I2_EXT: cig_push(&r, 'I', 1); off -= 1; k -= 1; s -= a.e2; comp = SRO_I2; break;
+            case BT_D1_OPEN: cig_push(&r, 'D', 1); k += 1; s -= a.o1 + a.e1; break;
+            case BT_D1_EXT: cig_push(&r, 'D', 1); k += 1; s -= a.e1; comp = SRO_D1; break;
+            case BT_D2_OPEN: cig_push(&r, 'D', 1); k += 1; s -= a.o2 + a.e2; break;
+            case BT_D2_EXT: cig_push(&r, 'D', 1); k += 1; s -= a.e2; comp = SRO_D2; break;
+            }
+        } else {
+            if (s == 0) {
+                /* begin component reached at the origin */
+                if (comp != cb || k != 0 || off != 0) ok = 0;
+                break;
+            }
+            const int is_ins = (comp == SRO_I1 || comp == SRO_I2);
+            const int o = (comp == SRO_I1 || comp == SRO_D1) ? a.o1 : a.o2;
+            const int e = (comp == SRO_I1 || comp == SRO_D1) ? a.e1 : a.e2;
+            const level_t *Lo = wfa_level(&a, s - o - e);
+            const level_t *Le = wfa_level(&a, s - e);
+            int32_t c_open, c_ext;
+            const uint32_t lim = (uint32_t)IMIN(tlen, plen + k);
+            if (is_ins) {
+                c_open = bnd(lv_get(Lo, SRO_M, k - 1) + 1, lim);
+                c_ext = bnd(lv_get(Le, comp, k - 1) + 1, lim);
+            } else {
+                c_open = bnd(lv_get(Lo, SRO_M, k + 1), lim);
+                c_ext = bnd(lv_get(Le, comp, k + 1), lim);
+            }
+            /* ext tag outranks open tag */
+            int take_ext;
+            if (c_ext >= 0 && c_ext >= c_open) take_ext = 1;
+            else if (c_open >= 0) take_ext = 0;
+            else { ok = 0; break; }
+            if ((take_ext ? c_ext : c_open) != off) { ok = 0; break; }
+            if (is_ins) { cig_push(&r, 'I', 1); off -= 1; k -= 1; }
+            else { cig_push(&r, 'D', 1); k += 1; }
+            if (take_ext) s -= e; else { s -= o + e; comp = SRO_M; }
+        }
+        if (s < 0) { ok = 0; break; }
+    }
+    if (ok) {
+        for (int i = r.n - 1; i >= 0; i--) cig_push(out, r.b[i], 1);
+    }
+    free(r.b);
+    if (cells) *cells += a.cells;
+    wfa_free(&a);
+    return ok ? score : -2;
+}
+
+/* ---------------- biWFA ---------------- */
+typedef struct {
+    int score, score_f, score_r, k_f, k_r, comp;
+    int32_t off_f, off_r;
+} bp_t;
+
+static int level_max_ak(const level_t *L) {
+    int mx = 0;
+    if (!L) return 0;
+    for (int k = L->lo; k <= L->hi; k++) {
+        int32_t o = L->c[SRO_M][k + L->off0];
+        if (o < 0) continue;
+        int ak = 2 * o - k;
+        if (ak > mx) mx = ak;
+    }
+    return mx;
+}
+
+/* breakpoint test on one component pair (m2m / indel2indel) */
+static void bp_check(const level_t *L0, const level_t *L1, int comp, int plen,
+                     int tlen, int score_0, int score_1, int gap_open,
+                     int bp_forward, bp_t *bp) {
+    /* L0, L1 non-null levels */
+    const int kinv = tlen - plen;
+    int lo_0 = L0->lo, hi_0 = L0->hi;
+    int lo_1 = kinv - L1->hi, hi_1 = kinv - L1->lo;
+    if (hi_1 < lo_0 || hi_0 < lo_1) return;
+    int min_hi = IMIN(hi_0, hi_1), max_lo = IMAX(lo_0, lo_1);
+    for (int k_0 = max_lo; k_0 <= min_hi; k_0++) {
+        const int k_1 = kinv - k_0;
+        const int32_t o0 = L0->c[comp][k_0 + L0->off0];
+        const int32_t o1 = L1->c[comp][k_1 + L1->off0];
+        if (o0 < 0 || o1 < 0) continue;   /* stored values are in-bounds or null */
+        if (o0 + o1 >= tlen && score_0 + score_1 - gap_open < bp->score) {
+            if (bp_forward) {
+                bp->score_f = score_0; bp->score_r = score_1;
+                bp->k_f = k_0; bp->k_r = k_1; bp->off_f = o0; bp->off_r = o1;
+            } else {
+                bp->score_f = score_1; bp->score_r = score_0;
+                bp->k_f = k_1; bp->k_r = k_0; bp->off_f = o1; bp->off_r = o0;
+            }
+            bp->score = score_0 + score_1 - gap_open;
+            bp->comp = comp;
+            return;
+        }
+    }
+}
+
+static void bialign_overlap(const wfa_t *a0, const wfa_t *a1, int score_0,
+                            int score_1, int bp_forward, bp_t *bp) {
+    const level_t *L0 = wfa_level(a0, score_0);
+    if (!L0) return;
+    const int plen = a0->w.plen, tlen = a0->w.tlen;
+    for (int i = 0; i < a0->scope; i++) {
+        const int score_i = score_1 - i;
+        if (score_i < 0) break;
+        const level_t *Li = wfa_level(a1, score_i);
+        if (a0->two && Li) {
+            if (score_0 + score_i - a0->o2 < bp->score) {
+                bp_check(L0, Li, SRO_D2, plen, tlen, score_0, score_i, a0->o2, bp_forward, bp);
+                bp_check(L0, Li, SRO_I2, plen, tlen, score_0, score_i, a0->o2, bp_forward, bp);
+            }
+        }
+        if (Li && score_0 + score_i - a0->o1 < bp->score) {
+            bp_check(L0, Li, SRO_D1, plen, tlen, score_0, score_i, a0->o1, bp_forward, bp);
+            bp_check(L0, Li, SRO_I1, plen, tlen, score_0, score_i, a0->o1, bp_forward, bp);
+        }
+        if (score_0 + score_i >= bp->score) continue;
+        if (Li) bp_check(L0, Li, SRO_M, plen, tlen, score_0, score_i, 0, bp_forward, bp);
+    }
+}
+
+static int bialign_find_breakpoint(const view_t *w, const sro_penalties *pen,
+                                   int cb, int ce, bp_t *bp, uint64_t *cells) {
+    wfa_t F, R;
+    view_t wr = *w; wr.rev = 1;
+    wfa_init(&F, w, pen, 1);
+    wfa_init(&R, &wr, pen, 1);
+    const int plen = w->plen, tlen = w->tlen;
+    const int max_antidiagonal = plen + tlen - 1;
+    const int scope = F.scope;
+    const int gap_opening = F.two ? IMAX(F.o1, F.o2) : F.o1;
+    long smax = 2L * ((long)F.o1 + (long)F.e1 * plen + (long)F.o1 + (long)F.e1 * tlen) + 1024;
+    int score_f = 0, score_r = 0;
+    bp->score = INT_MAX;
+    wfa_level0(&F, cb);
+    wfa_level0(&R, ce);
+    int f_max_ak = level_max_ak(wfa_level(&F, 0));
+    int r_max_ak = level_max_ak(wfa_level(&R, 0));
+    int last_wf_forward = 0;
+    int status = 0;
+    for (;;) {
+        if (f_max_ak + r_max_ak >= max_antidiagonal) break;
+        ++score_f;
+        wfa_step(&F, score_f);
+        f_max_ak = level_max_ak(wfa_level(&F, score_f));
+        last_wf_forward = 1;
+        if (f_max_ak + r_max_ak >= max_antidiagonal) break;
+        ++score_r;
+        wfa_step(&R, score_r);
+        r_max_ak = level_max_ak(wfa_level(&R, score_r));
+        last_wf_forward = 0;
+        if (score_f + score_r > smax) { status = -1; break; }
+    }
+    while (status == 0) {
+        if (last_wf_forward) {
+            const int min_score_r = (score_r > scope - 1) ? score_r - (scope - 1) : 0;
+            if (score_f + min_score_r - gap_opening >= bp->score) break;
+            bialign_overlap(&F, &R, score_f, score_r, 1, bp);
+            ++score_r;
+            wfa_step(&R, score_r);
+        }
+        const int min_score_f = (score_f > scope - 1) ? score_f - (scope - 1) : 0;
+        if (min_score_f + score_r - gap_opening >= bp->score) break;
+        bialign_overlap(&R, &F, score_r, score_f, 0, bp);
+        ++score_f;
+        wfa_step(&F, score_f);
+        last_wf_forward = 1;
+        if (score_f + score_r > smax) { status = -1; break; }
+    }
+    if (cells) *cells += F.cells + R.cells;
+    wfa_free(&F);
+    wfa_free(&R);
+    if (status == 0 && bp->score == INT_MAX) status = -1;
+    return status;
+}
+
+static int bialign(const uint8_t *p, int pb, int pe, const uint8_t *t, int tb,
+                   int te, const sro_penalties *pen, int cb, int ce,
+                   int score_remaining, cig_t *out, uint64_t *cells, int depth) {
+    const int plen = pe - pb, tlen = te - tb;
+    if (tlen == 0) { cig_push(out, 'D', plen); return 0; }
+    if (plen == 0) { cig_push(out, 'I', tlen); return 0; }
+    view_t w = { p + pb, t + tb, plen, tlen, 0 };
+    if (score_remaining <= SRO_BIALIGN_FALLBACK_MIN_SCORE ||
+        IMAX(plen, tlen) <= SRO_BIALIGN_FALLBACK_MIN_LENGTH || depth > 60) {
+        int sc = wfa_full(&w, pen, cb, ce, out, cells);
+        return sc < 0 ? sc : 0;
+    }
+    bp_t bp;
+    int st = bialign_find_breakpoint(&w, pen, cb, ce, &bp, cells);
+    if (st < 0) return st;
+    const int bh = bp.off_f;
+    const int bv = bp.off_f - bp.k_f;
+    if (bv < 0 || bv > plen || bh < 0 || bh > tlen) return -3;
+    st = bialign(p, pb, pb + bv, t, tb, tb + bh, pen, cb, bp.comp, bp.score_f,
+                 out, cells, depth + 1);
+    if (st < 0) return st;
+    st = bialign(p, pb + bv, pe, t, tb + bh, te, pen, bp.comp, ce, bp.score_r,
+                 out, cells, depth + 1);
+    return st;
+}
+
+/* ---------------- public entry points ---------------- */
+static int pen_valid(const sro_penalties *pen) {
+    if (pen->match != 0) return 0;             /* only match == 0 restated */
+    if (pen->mismatch <= 0 || pen->gap_open1 < 0 || pen->gap_ext1 <= 0) return 0;
+    if (pen->gap_open2 >= 0 && pen->gap_ext2 <= 0) return 0;
+    return 1;
+}
+
+int sro_cigar_score(const uint8_t *cigar, int n, const uint8_t *pattern,
+                    int plen, const uint8_t *text, int tlen,
+                    const sro_penalties *pen) {
+    int v = 0, h = 0, score = 0, i = 0;
+    const int two = pen->gap_open2 >= 0;
+    while (i < n) {
+        uint8_t op = cigar[i];
+        int j = i;
+        while (j < n && cigar[j] == op) j++;
+        int len = j - i;
+        if (op == 'M') {
+            for (int q = 0; q < len; q++) {
+                if (v >= plen || h >= tlen || pattern[v] != text[h]) return -1;
+                v++; h++;
+            }
+        } else if (op == 'X') {
+            for (int q = 0; q < len; q++) {
+                if (v >= plen || h >= tlen || pattern[v] == text[h]) return -1;
+                v++; h++;
+            }
+            score += len * pen->mismatch;
+        } else if (op == 'I' || op == 'D') {
+            int g = pen->gap_open1 + pen->gap_ext1 * len;
+            if (two) g = IMIN(g, pen->gap_open2 + pen->gap_ext2 * len);
+            score += g;
+            if (op == 'I') h += len; else v += len;
+        } else return -1;
+        i = j;
+    }
+    if (v != plen || h != tlen) return -1;
+    return score;
+}
+
+int sro_wfa_align(const uint8_t *pattern, int plen, const uint8_t *text,
+                  int tlen, const sro_penalties *pen, int memory_mode,
+                  uint8_t **cigar, int *cigar_len, int *score) {
+    if (!pen_valid(pen) || plen < 0 || tlen < 0) return -1;
+    cig_t out = {0, 0, 0};
+    uint64_t cells = 0;
+    int st;
+    if (plen == 0 || tlen == 0) {
+        cig_push(&out, 'D', plen);
+        cig_push(&out, 'I', tlen);
+        st = 0;
+    } else if (memory_mode == SRO_MEM_ULTRALOW) {
+        st = bialign(pattern, 0, plen, text, 0, tlen, pen, SRO_M, SRO_M,
+                     INT_MAX, &out, &cells, 0);
+    } else {
+        view_t w = { pattern, text, plen, tlen, 0 };
+        st = wfa_full(&w, pen, SRO_M, SRO_M, &out, &cells);
+        if (st >= 0) st = 0;
+    }
+    g_last_cells = cells;
+    if (st < 0) { free(out.b); return st; }
+    if (score) *score = sro_cigar_score(out.b, out.n, pattern, plen, text, tlen, pen);
+    if (cigar) { *cigar = out.b ? out.b : (uint8_t *)malloc(1); } else free(out.b);
+    if (cigar_len) *cigar_len = out.n;
+    return 0;
+}
+
+int sro_wfa_score(const uint8_t *pattern, int plen, const uint8_t *text,
+                  int tlen, const sro_penalties *pen, int max_score,
+                  int *score) {
+    if (!pen_valid(pen) || plen <= 0 || tlen <= 0) return -1;
+    view_t w = { pattern, text, plen, tlen, 0 };
+    wfa_t a;
+    wfa_init(&a, &w, pen, 1);
+    const int k_end = tlen - plen;
+    long smax = (long)a.o1 + (long)a.e1 * plen + (long)a.o1 + (long)a.e1 * tlen + 64;
+    wfa_level0(&a, SRO_M);
+    int s = 0, res = INT_MAX;
+    for (;;) {
+        const level_t *L = wfa_level(&a, s);
+        if (L && lv_get(L, SRO_M, k_end) >= tlen) { res = s; break; }
+        if (s > smax) break;
+        if (max_score >= 0 && s >= max_score) break;
+        s++;
+        wfa_step(&a, s);
+    }
+    g_last_cells = a.cells;
+    wfa_free(&a);
+    *score = res;
+    return 0;
+}
+
+/* ---------------- independent Gotoh 2-piece affine DP ---------------- */
+int sro_gotoh_score(const uint8_t *pattern, int plen, const uint8_t *text,
+                    int tlen, const sro_penalties *pen) {
+    const int INF = INT_MAX / 4;
+    const int two = pen->gap_open2 >= 0;
+    const int x = pen->mismatch, o1 = pen->gap_open1, e1 = pen->gap_ext1;
+    const int o2 = two ? pen->gap_open2 : 0, e2 = two ? pen->gap_ext2 : 0;
+    size_t n = (size_t)tlen + 1;
+    int *M = (int *)malloc(sizeof(int) * n), *I1 = (int *)malloc(sizeof(int) * n),
+        *I2 = (int *)malloc(sizeof(int) * n), *D1 = (int *)malloc(sizeof(int) * n),
+        *D2 = (int *)malloc(sizeof(int) * n);
+    /* row 0 */
+    M[0] = 0; I1[0] = I2[0] = D1[0] = D2[0] = INF;
+    for (int h = 1; h <= tlen; h++) {
+        I1[h] = IMIN(M[h - 1] + o1 + e1, I1[h - 1] + e1);
+        I2[h] = two ? IMIN(M[h - 1] + o2 + e2, I2[h - 1] + e2) : INF;
+        D1[h] = D2[h] = INF;
+        M[h] = IMIN(I1[h], I2[h]);
+    }
+    for (int v = 1; v <= plen; v++) {
+        int diag = M[0];          /* M[v-1][0] */
+        /* column 0 */
+        int d1 = IMIN(M[0] + o1 + e1, D1[0] + e1);
+        int d2 = two ? IMIN(M[0] + o2 + e2, D2[0] + e2) : INF;
+        D1[0] = d1; D2[0] = d2; I1[0] = I2[0] = INF;
+        M[0] = IMIN(d1, d2);
+        for (int h = 1; h <= tlen; h++) {
+            int up = M[h];        /* M[v-1][h] */
+            int nd1 = IMIN(up + o1 + e1, D1[h] + e1);
+            int nd2 = two ? IMIN(up + o2 + e2, D2[h] + e2) : INF;
+            int ni1 = IMIN(M[h - 1] + o1 + e1, I1[h - 1] + e1);
+            int ni2 = two ? IMIN(M[h - 1] + o2 + e2, I2[h - 1] + e2) : INF;
+            int sub = diag + (pattern[v - 1] == text[h - 1] ? 0 : x);
+            int m = IMIN(sub, IMIN(IMIN(nd1, nd2), IMIN(ni1, ni2)));
+            diag = up;
+            D1[h] = nd1; D2[h] = nd2; I1[h] = ni1; I2[h] = ni2; M[h] = m;
+        }
+    }
+    int res = M[tlen];
+    free(M); free(I1); free(I2); free(D1); free(D2);
+    return res;
+}
+
+/* cigar_bytes_to_string: src/wfa.rs:9-38 */
+char *sro_cigar_bytes_to_string(const uint8_t *cigar_bytes, int n) {
+    size_t cap = 64, len = 0;
+    char *s = (char *)malloc(cap);
+    int i = 0;
+    while (i < n) {
+        uint8_t op = cigar_bytes[i];
+        int count = 1, j = i + 1;
+        while (j < n && cigar_bytes[j] == op) { count++; j++; }
+        char op_char;
+        switch (op) {
+        case 'M': op_char = '='; break;
+        case 'X': op_char = 'X'; break;
+        case 'I': op_char = 'D'; break;   /* WFA2 'I' means standard 'D' */
+        case 'D': op_char = 'I'; break;   /* WFA2 'D' means standard 'I' */
+        default: op_char = '?'; break;
+        }
+        if (len + 24 > cap) { cap *= 2; s = (char *)realloc(s, cap); }
+        len += (size_t)snprintf(s + len, cap - len, "%d%c", count, op_char);
+        i = j;
+    }
+    s[len] = 0;
+    return s;
+}
