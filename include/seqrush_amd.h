@@ -1,0 +1,181 @@
+/*
+ * seqrush_amd.h -- C ABI of the MI355X-native seqrush hot path
+ * (all-vs-all WFA2/biWFA alignment -> match-run extraction -> lock-free
+ * bidirected union-find).  Plain pointers and sizes only; no torch types.
+ *
+ * Each entry point names the reference interface it replaces (paths relative
+ * to the pangenome/seqrush checkout).  INTEGRATION.md shows the Rust
+ * `extern "C"` binding a seqrush maintainer would add.
+ *
+ * Error model: every int-returning function returns 0 on success or a
+ * negative sr_status; sr_last_error() gives a thread-local message.  Nothing
+ * here falls back to a CPU path: without a HIP device every compute entry
+ * point fails with SR_ERR_NO_DEVICE.
+ */
+#ifndef SEQRUSH_AMD_H
+#define SEQRUSH_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SR_ABI_VERSION 1
+
+typedef enum {
+    SR_OK = 0,
+    SR_ERR_INVALID = -1,      /* bad argument / parse error */
+    SR_ERR_NO_DEVICE = -2,    /* no HIP device or HIP runtime failure at init */
+    SR_ERR_HIP = -3,          /* a HIP call failed */
+    SR_ERR_ALPHABET = -4,     /* sequence byte outside the packable alphabet */
+    SR_ERR_EMPTY_SEQ = -5,    /* "Empty sequences are not allowed" seqrush.rs:310-317 */
+    SR_ERR_UNSUPPORTED = -6,  /* parameter combination not implemented on device */
+    SR_ERR_DEVICE_FAULT = -7, /* kernel reported an internal bound violation */
+    SR_ERR_IO = -8,
+    SR_ERR_NOMEM = -9
+} sr_status;
+
+/* -------- inputs --------------------------------------------------------
+ * sr_seqset mirrors `&[AlignmentSequence]` (src/aligner.rs:5-9) /
+ * `Vec<Sequence{id,data,offset}>` (src/seqrush.rs:272-277): concatenated
+ * bases + offsets[n+1] (offset = running sum, seqrush.rs:1818) + names. */
+typedef struct {
+    uint32_t n;
+    const uint8_t *bases;         /* offsets[n] bytes */
+    const uint64_t *offsets;      /* n+1 entries, offsets[0] = 0 */
+    const char *const *names;     /* n C strings (may be NULL for unite-only use) */
+} sr_seqset;
+
+/* lib_wfa2 MemoryMode as used by src/wfa.rs:57,65 */
+#define SR_MEM_HIGH 0
+#define SR_MEM_ULTRALOW 3
+
+/* SparsificationStrategy (grammar src/seqrush.rs:356-431) */
+#define SR_SPARSE_NONE 0
+#define SR_SPARSE_AUTO 1
+#define SR_SPARSE_RANDOM 2
+#define SR_SPARSE_CONNECTIVITY 3
+#define SR_SPARSE_TREE 4
+
+/* sr_params mirrors allwave::AlignmentParams (src/seqrush.rs:648-666) plus
+ * the Args fields the hot path reads (-k, -d, -x; src/seqrush.rs:24-151). */
+typedef struct {
+    int32_t match_score;        /* must be 0 */
+    int32_t mismatch_penalty;   /* -S default 0,5,8,2,24,1 (seqrush.rs:45) */
+    int32_t gap_open1, gap_ext1;
+    int32_t gap_open2, gap_ext2;        /* < 0 : single-piece affine */
+    int32_t ori_match, ori_mismatch, ori_gap_open, ori_gap_ext; /* 0,1,1,1 (:49) */
+    uint64_t min_match_len;     /* -k (:33), run united iff len >= k (:1311) */
+    double max_divergence;      /* -d, < 0 = None */
+    int32_t exclude_self;       /* reference passes false (:731) */
+    int32_t memory_mode;        /* SR_MEM_ULTRALOW = reference (wfa.rs:57) */
+    int32_t sparsify_kind;      /* SR_SPARSE_* ; only NONE/RANDOM on device */
+    double sparsify_factor;
+    uint64_t sparsify_seed;
+    int32_t canonical_labels;   /* sr_align_and_unite: 1 = return min-Pos labels */
+    int32_t device;             /* HIP device ordinal */
+    /* pair shard for multi-GPU: this call handles ordered pairs whose index
+     * in the (sparsified) row-major n*n list is == shard_rank mod shard_count */
+    uint32_t shard_rank, shard_count;
+} sr_params;
+
+void sr_default_params(sr_params *p);
+/* AlignmentScores::parse seqrush.rs:165-217 / parse_orientation :219-250 */
+int sr_parse_scores(const char *s, sr_params *p);
+int sr_parse_orientation_scores(const char *s, sr_params *p);
+/* parse_sparsification seqrush.rs:356-431 */
+int sr_parse_sparsification(const char *s, sr_params *p);
+
+/* -------- Seam 1: trait Aligner (src/aligner.rs:27-33) -----------------
+ * sr_align_all == AllwaveAligner::align_sequences
+ * (src/aligner/allwave_impl.rs:95-149): one call, all sequences, returns one
+ * record per ordered pair (self pairs included unless exclude_self). */
+typedef struct {
+    uint64_t n;                 /* number of alignments */
+    uint32_t *query_idx, *target_idx;
+    uint8_t *is_reverse;        /* strand '-' <=> 1 (aligner.rs:18) */
+    int32_t *score;
+    uint64_t *query_start, *query_end, *target_start, *target_end;
+    uint64_t *cigar_off;        /* n+1 offsets into cigar_ops */
+    uint32_t *cigar_ops;        /* (len << 4) | op ; op: 0 '=' 1 'X' 2 'I' 3 'D'
+                                   in the reference's converted alphabet
+                                   (src/wfa.rs:25-31: I = query-only, D = target-only) */
+} sr_alignments;
+
+int sr_align_all(const sr_seqset *seqs, const sr_params *p, sr_alignments **out);
+void sr_alignments_free(sr_alignments *a);
+/* CIGAR string of alignment i ("159=1X75=..."), == cigar_bytes_to_string
+ * (src/wfa.rs:9-38).  Returns needed length (excl. NUL); writes up to cap. */
+size_t sr_alignment_cigar(const sr_alignments *a, uint64_t i, char *buf, size_t cap);
+
+/* -------- Seam 2: fused production path ---------------------------------
+ * == SeqRush::new (seqrush.rs:308-336) + align_and_unite_with_allwave
+ * (seqrush.rs:611-757): alignment + process_alignment (:1134-1481) +
+ * BidirectedUnionFind::unite_matching_region (bidirected_union_find.rs:60-98)
+ * entirely on device.  parent_out has 2*N+2 entries: the uf_rush node array
+ * (parent | rank << 58, uf_rush lib.rs:228-240) or, with canonical_labels,
+ * the minimum Pos of each element's component. */
+int sr_align_and_unite(const sr_seqset *seqs, const sr_params *p, uint64_t *parent_out);
+
+/* uf_rush find/same over a returned node array (host side, read-only, no
+ * path compression): UFRush::find lib.rs:112-133, same :72-84 */
+uint64_t sr_uf_find(const uint64_t *nodes, uint64_t n, uint64_t x);
+int sr_uf_same(const uint64_t *nodes, uint64_t n, uint64_t x, uint64_t y);
+
+/* -------- Seam 3: PAF interchange (seqrush.rs:510-609, 678-716) -------- */
+int sr_write_paf(const sr_alignments *a, const sr_seqset *seqs, const char *path);
+
+/* -------- resident-context API (what bench.py times) --------------------
+ * Same path split so inputs can stay in HBM across calls. */
+typedef struct sr_ctx sr_ctx;
+int sr_ctx_create(int device, sr_ctx **out);
+void sr_ctx_destroy(sr_ctx *c);
+/* optional: launch on an externally owned hipStream_t */
+int sr_ctx_set_stream(sr_ctx *c, void *hip_stream);
+/* pack (2-bit fwd + reverse complement) and upload; SeqRush::new UF init */
+int sr_ctx_load(sr_ctx *c, const sr_seqset *seqs, const sr_params *p);
+/* reset the UF to the SeqRush::new state (seqrush.rs:324-328) */
+int sr_ctx_reset_uf(sr_ctx *c);
+/* enqueue alignment kernel(s) for this rank's pair shard (no host sync) */
+int sr_ctx_align(sr_ctx *c);
+/* enqueue match-run extraction + unite kernel (no host sync) */
+int sr_ctx_unite(sr_ctx *c);
+int sr_ctx_sync(sr_ctx *c);     /* stream sync + device error flags */
+/* results */
+int sr_ctx_alignments(sr_ctx *c, sr_alignments **out);       /* after sync */
+int sr_ctx_download_uf(sr_ctx *c, uint64_t *parent_out);     /* raw nodes */
+uint64_t sr_ctx_uf_size(const sr_ctx *c);                    /* 2N+2 */
+uint64_t sr_ctx_num_pairs(const sr_ctx *c);                  /* this shard */
+uint64_t sr_ctx_dp_cells(const sr_ctx *c);   /* sum |q|*|t| over this shard */
+/* multi-GPU merge: canonical min-Pos labels of the local forest
+ * written to a DEVICE buffer of uf_size u64 (e.g. a torch tensor's data_ptr);
+ * sr_ctx_merge_labels replays unite(i, labels[i]) for `count` gathered arrays
+ * laid out back to back in DEVICE memory. */
+int sr_ctx_labels_device(sr_ctx *c, uint64_t *dev_labels);
+int sr_ctx_merge_labels(sr_ctx *c, const uint64_t *dev_labels, uint32_t count);
+int sr_ctx_download_labels(sr_ctx *c, uint64_t *labels_out);
+/* timing of the last enqueued kernels, measured with hipEvents on the
+ * context's stream: which = 0 align, 1 unite, 2 labels/merge */
+int sr_ctx_kernel_ms(sr_ctx *c, int which, float *ms);
+/* device counters accumulated by the last align: [0] wavefront cells,
+ * [1] wavefront steps, [2] base-case segments, [3] breakpoint searches,
+ * [4] united bases (after unite), [5] match runs */
+int sr_ctx_counters(sr_ctx *c, uint64_t out[8]);
+
+/* -------- consumer (A9): graph induction + GFA, host C++ -----------------
+ * build_bidirected_graph_with_options (bidirected_builder.rs:17-289) +
+ * write_gfa (bidirected_ops.rs:880-925) for --no-sort --no-compact, from
+ * canonical labels.  Returns malloc'd text in *gfa (free with sr_free). */
+int sr_build_gfa(const sr_seqset *seqs, const uint64_t *labels, char **gfa,
+                 uint64_t *n_nodes, uint64_t *n_edges);
+void sr_free(void *p);
+
+const char *sr_last_error(void);
+int sr_abi_version(void);
+int sr_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,757 @@
+// sr_host.cpp -- host side of the C ABI declared in include/seqrush_amd.h.
+// Packs sequences (2-bit, forward + reverse complement), builds the ordered
+// pair list, owns device memory / stream / events and launches the kernels of
+// sr_device.hip.  No CPU alignment path exists here: without a HIP device the
+// compute entry points fail with SR_ERR_NO_DEVICE.
+#include <hip/hip_runtime_api.h>
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+#include "../../include/seqrush_amd.h"
+#include "sr_internal.h"
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+extern "C" const char *sr_last_error(void) { return g_err.c_str(); }
+extern "C" int sr_abi_version(void) { return SR_ABI_VERSION; }
+extern "C" void sr_free(void *p) { free(p); }
+extern "C" int sr_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+#define HIPCHK(expr)                                                                     \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess)                                                            \
+            return fail(SR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));  \
+    } while (0)
+
+// ------------------------------------------------------------------ params
+extern "C" void sr_default_params(sr_params *p) {
+    memset(p, 0, sizeof(*p));
+    p->match_score = 0; p->mismatch_penalty = 5; p->gap_open1 = 8; p->gap_ext1 = 2;
+    p->gap_open2 = 24; p->gap_ext2 = 1;                         // seqrush.rs:45
+    p->ori_match = 0; p->ori_mismatch = 1; p->ori_gap_open = 1; p->ori_gap_ext = 1;  // :49
+    p->min_match_len = 0; p->max_divergence = -1.0; p->exclude_self = 0;
+    p->memory_mode = SR_MEM_ULTRALOW; p->sparsify_kind = SR_SPARSE_NONE; p->sparsify_factor = 1.0;
+    p->sparsify_seed = 42; p->canonical_labels = 0; p->device = 0;
+    p->shard_rank = 0; p->shard_count = 1;
+}
+
+static bool parse_i32(const std::string &s, int32_t *out) {     // Rust str::parse::<i32>
+    if (s.empty() || s.size() > 15) return false;
+    size_t i = (s[0] == '+' || s[0] == '-') ? 1 : 0;
+    if (i == s.size()) return false;
+    for (size_t j = i; j < s.size(); j++) if (s[j] < '0' || s[j] > '9') return false;
+    long long v = atoll(s.c_str());
+    if (v > INT32_MAX || v < INT32_MIN) return false;
+    *out = (int32_t)v;
+    return true;
+}
+static std::vector<std::string> split(const std::string &s, char c) {
+    std::vector<std::string> out;
+    size_t st = 0;
+    for (;;) {
+        size_t p = s.find(c, st);
+        if (p == std::string::npos) { out.push_back(s.substr(st)); break; }
+        out.push_back(s.substr(st, p - st));
+        st = p + 1;
+    }
+    return out;
+}
+
+extern "C" int sr_parse_scores(const char *s, sr_params *p) {   // seqrush.rs:165-217
+    auto parts = split(s, ',');
+    if (parts.size() < 4)
+        return fail(SR_ERR_INVALID, "Scores must have at least 4 values: match,mismatch,gap1_open,gap1_extend");
+    if (parts.size() > 6) return fail(SR_ERR_INVALID, "Too many score values provided (max 6)");
+    int32_t v[6] = {0, 0, 0, 0, -1, -1};
+    static const char *nm[6] = {"match score", "mismatch penalty", "gap1_open penalty",
+                                "gap1_extend penalty", "gap2_open penalty", "gap2_extend penalty"};
+    for (int i = 0; i < 4; i++)
+        if (!parse_i32(parts[i], &v[i])) return fail(SR_ERR_INVALID, std::string("Invalid ") + nm[i] + ": " + parts[i]);
+    if (parts.size() >= 6)
+        for (int i = 4; i < 6; i++)
+            if (!parse_i32(parts[i], &v[i])) return fail(SR_ERR_INVALID, std::string("Invalid ") + nm[i] + ": " + parts[i]);
+    p->match_score = v[0]; p->mismatch_penalty = v[1]; p->gap_open1 = v[2]; p->gap_ext1 = v[3];
+    p->gap_open2 = v[4]; p->gap_ext2 = v[5];
+    return SR_OK;
+}
+
+extern "C" int sr_parse_orientation_scores(const char *s, sr_params *p) {   // :219-250
+    auto parts = split(s, ',');
+    if (parts.size() != 4)
+        return fail(SR_ERR_INVALID, "Orientation scores must have exactly 4 values: match,mismatch,gap_open,gap_extend");
+    int32_t v[4];
+    for (int i = 0; i < 4; i++)
+        if (!parse_i32(parts[i], &v[i])) return fail(SR_ERR_INVALID, "Invalid orientation score: " + parts[i]);
+    p->ori_match = v[0]; p->ori_mismatch = v[1]; p->ori_gap_open = v[2]; p->ori_gap_ext = v[3];
+    return SR_OK;
+}
+
+static bool parse_f64(const std::string &s, double *out) {
+    if (s.empty() || isspace((unsigned char)s[0])) return false;
+    char *end;
+    double v = strtod(s.c_str(), &end);
+    if (*end != 0) return false;
+    *out = v;
+    return true;
+}
+
+extern "C" int sr_parse_sparsification(const char *cs, sr_params *p) {      // :356-431
+    std::string s(cs);
+    if (s == "none" || s == "1.0") { p->sparsify_kind = SR_SPARSE_NONE; return SR_OK; }
+    if (s == "auto") { p->sparsify_kind = SR_SPARSE_AUTO; return SR_OK; }
+    double f;
+    if (s.rfind("random:", 0) == 0) {
+        if (!parse_f64(s.substr(7), &f)) return fail(SR_ERR_INVALID, "Invalid random factor: " + s);
+        if (f > 0.0 && f <= 1.0) { p->sparsify_kind = SR_SPARSE_RANDOM; p->sparsify_factor = f; return SR_OK; }
+        return fail(SR_ERR_INVALID, "Random factor must be in (0.0, 1.0]");
+    }
+    if (s.rfind("connectivity:", 0) == 0) {
+        if (!parse_f64(s.substr(13), &f)) return fail(SR_ERR_INVALID, "Invalid connectivity probability: " + s);
+        if (f > 0.0 && f <= 1.0) { p->sparsify_kind = SR_SPARSE_CONNECTIVITY; p->sparsify_factor = f; return SR_OK; }
+        return fail(SR_ERR_INVALID, "Connectivity probability must be in (0.0, 1.0]");
+    }
+    if (s.rfind("tree:", 0) == 0) {
+        auto parts = split(s.substr(5), ',');
+        if (parts.empty() || parts.size() > 4) return fail(SR_ERR_INVALID, "Tree sampling requires 1-4 values");
+        for (size_t i = 0; i < parts.size(); i++) {
+            double d;
+            if (!parse_f64(parts[i], &d)) return fail(SR_ERR_INVALID, "Invalid tree parameter: " + parts[i]);
+        }
+        p->sparsify_kind = SR_SPARSE_TREE;
+        return SR_OK;
+    }
+    if (parse_f64(s, &f) && f > 0.0 && f <= 1.0) { p->sparsify_kind = SR_SPARSE_RANDOM; p->sparsify_factor = f; return SR_OK; }
+    return fail(SR_ERR_INVALID, "Invalid sparsification: '" + s + "'");
+}
+
+// max_score_for_divergence seqrush.rs:253-269
+static int32_t max_score_for_divergence(const sr_params &p, uint64_t seq_len, double d) {
+    int32_t max_mismatches = (int32_t)std::ceil((double)seq_len * d);
+    int32_t max_gaps = (int32_t)std::ceil((double)seq_len * d * 0.5);
+    int32_t mismatch_score = max_mismatches * p.mismatch_penalty;
+    int32_t gap_score = max_gaps > 0 ? p.gap_open1 + (max_gaps - 1) * p.gap_ext1 : 0;
+    return std::max(mismatch_score + gap_score, p.mismatch_penalty * 2);
+}
+
+// ------------------------------------------------------------------ context
+struct sr_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    sr_params prm;
+    uint32_t n = 0;
+    std::vector<uint32_t> len;
+    std::vector<uint64_t> goff;
+    uint64_t total_len = 0, uf_size = 0;
+    std::vector<uint32_t> pair_q, pair_t;
+    std::vector<uint64_t> cigar_base;
+    uint64_t dp_cells = 0;
+    int off16 = 1, nwg = 0;
+    size_t lds_bytes = 0;
+    SrAlignArgs aa{};
+    SrUniteArgs ua{};
+    std::vector<void *> dev_allocs;
+    unsigned long long *d_nodes = nullptr, *d_minarr = nullptr, *d_labels = nullptr;
+    unsigned long long *d_counters = nullptr;
+    int *d_error = nullptr;
+    uint32_t *d_queue = nullptr;
+    int32_t *d_max_score = nullptr;
+    hipEvent_t ev[3][2]{};
+    bool ev_valid[3] = {false, false, false};
+    bool loaded = false;
+};
+
+static int dev_alloc(sr_ctx *c, void **p, size_t bytes) {
+    HIPCHK(hipMalloc(p, bytes ? bytes : 16));
+    c->dev_allocs.push_back(*p);
+    return SR_OK;
+}
+static void free_dev(sr_ctx *c) {
+    for (void *p : c->dev_allocs) (void)hipFree(p);
+    c->dev_allocs.clear();
+    c->d_nodes = c->d_minarr = c->d_labels = c->d_counters = nullptr;
+    c->d_error = nullptr; c->d_queue = nullptr; c->d_max_score = nullptr;
+    c->loaded = false;
+}
+
+extern "C" int sr_ctx_create(int device, sr_ctx **out) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
+        return fail(SR_ERR_NO_DEVICE, "no HIP device available (seqrush_amd has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(SR_ERR_INVALID, "device ordinal out of range");
+    HIPCHK(hipSetDevice(device));
+    sr_ctx *c = new sr_ctx();
+    c->device = device;
+    if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return fail(SR_ERR_HIP, "hipStreamCreate failed"); }
+    c->own_stream = true;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 2; j++)
+            if (hipEventCreate(&c->ev[i][j]) != hipSuccess) { delete c; return fail(SR_ERR_HIP, "hipEventCreate failed"); }
+    *out = c;
+    return SR_OK;
+}
+
+extern "C" void sr_ctx_destroy(sr_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_dev(c);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 2; j++) if (c->ev[i][j]) (void)hipEventDestroy(c->ev[i][j]);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int sr_ctx_set_stream(sr_ctx *c, void *hip_stream) {
+    if (!c) return fail(SR_ERR_INVALID, "null ctx");
+    if (c->own_stream && c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    c->stream = (hipStream_t)hip_stream;
+    c->own_stream = false;
+    return SR_OK;
+}
+
+static inline int code2(uint8_t b) {
+    switch (b) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return -1; }
+}
+static inline uint8_t comp_base(uint8_t b) {      // Sequence::reverse_complement seqrush.rs:281-295
+    switch (b) {
+    case 'A': case 'a': return 'T'; case 'T': case 't': return 'A';
+    case 'C': case 'c': return 'G'; case 'G': case 'g': return 'C';
+    default: return b;
+    }
+}
+
+static uint64_t splitmix64(uint64_t x) {
+    x += 0x9e3779b97f4a7c15ULL;
+    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    x = (x ^ (x >> 27)) * 0x94d049bb133111ebULL;
+    return x ^ (x >> 31);
+}
+
+static int make_pen(const sr_params &p, bool ori, SrPen *out) {
+    if (ori) {
+        if (p.ori_match != 0) return fail(SR_ERR_UNSUPPORTED, "orientation match score must be 0");
+        out->x = p.ori_mismatch; out->o1 = p.ori_gap_open; out->e1 = p.ori_gap_ext;
+        out->o2 = 0; out->e2 = 0; out->two = 0;
+    } else {
+        if (p.match_score != 0) return fail(SR_ERR_UNSUPPORTED, "match score must be 0 (WFA2 penalties, seqrush.rs:45)");
+        out->x = p.mismatch_penalty; out->o1 = p.gap_open1; out->e1 = p.gap_ext1;
+        out->two = p.gap_open2 >= 0;
+        out->o2 = out->two ? p.gap_open2 : 0; out->e2 = out->two ? p.gap_ext2 : 0;
+        if (out->two && out->e2 <= 0) return fail(SR_ERR_INVALID, "gap2_extend must be > 0");
+    }
+    if (out->x <= 0 || out->o1 < 0 || out->e1 <= 0) return fail(SR_ERR_INVALID, "penalties must satisfy x>0, o>=0, e>0");
+    out->scope = std::max(out->x, out->o1 + out->e1);
+    if (out->two) out->scope = std::max(out->scope, out->o2 + out->e2);
+    out->scope += 1;
+    if (out->scope > SR_MAX_SCOPE) return fail(SR_ERR_UNSUPPORTED, "penalties too large for the device ring (scope > 128)");
+    return SR_OK;
+}
+
+extern "C" int sr_ctx_load(sr_ctx *c, const sr_seqset *seqs, const sr_params *p) {
+    if (!c || !seqs || !p) return fail(SR_ERR_INVALID, "null argument");
+    if (seqs->n == 0) return fail(SR_ERR_INVALID, "no sequences");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    free_dev(c);
+    c->prm = *p;
+    const uint32_t n = seqs->n;
+    c->n = n;
+    c->len.assign(n, 0); c->goff.assign(n, 0);
+    uint64_t maxlen = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint64_t L = seqs->offsets[i + 1] - seqs->offsets[i];
+        if (L == 0) {
+            std::string nm = (seqs->names && seqs->names[i]) ? seqs->names[i] : std::to_string(i);
+            return fail(SR_ERR_EMPTY_SEQ, "Empty sequences are not allowed: sequence '" + nm + "' has length 0");
+        }
+        if (L > 0x7fff0000ULL) return fail(SR_ERR_UNSUPPORTED, "sequence too long");
+        c->len[i] = (uint32_t)L; c->goff[i] = seqs->offsets[i];
+        maxlen = std::max(maxlen, L);
+    }
+    c->total_len = seqs->offsets[n];
+    c->uf_size = (c->total_len << 1) + 2;          // bidirected_union_find.rs:16-24
+    SrPen pen, ori;
+    int r;
+    if ((r = make_pen(*p, false, &pen))) return r;
+    if ((r = make_pen(*p, true, &ori))) return r;
+    if (p->memory_mode != SR_MEM_ULTRALOW && p->memory_mode != SR_MEM_HIGH)
+        return fail(SR_ERR_UNSUPPORTED, "memory_mode must be SR_MEM_ULTRALOW or SR_MEM_HIGH");
+    if (p->sparsify_kind != SR_SPARSE_NONE && p->sparsify_kind != SR_SPARSE_RANDOM)
+        return fail(SR_ERR_UNSUPPORTED, "only sparsification none / random:F is implemented on device");
+    if (p->shard_count == 0 || p->shard_rank >= p->shard_count) return fail(SR_ERR_INVALID, "bad shard");
+    // ---- pack 2-bit forward + reverse complement, one pad word either side
+    std::vector<uint64_t> woff_f(n), woff_r(n);
+    uint64_t words = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint64_t w = (c->len[i] + 15) / 16;
+        woff_f[i] = words + 1; words += w + 2;
+        woff_r[i] = words + 1; words += w + 2;
+    }
+    std::vector<uint32_t> packed(words, 0);
+    for (uint32_t i = 0; i < n; i++) {
+        const uint8_t *b = seqs->bases + seqs->offsets[i];
+        const uint64_t L = c->len[i];
+        for (uint64_t j = 0; j < L; j++) {
+            const int cf = code2(b[j]);
+            const int cr = code2(comp_base(b[L - 1 - j]));
+            if (cf < 0 || cr < 0)
+                return fail(SR_ERR_ALPHABET, "sequence byte outside upper-case ACGT: the 2-bit device path cannot "
+                                             "represent it (reference compares raw bytes, seqrush.rs:1269-1283)");
+            packed[woff_f[i] + (j >> 4)] |= (uint32_t)cf << ((j & 15) * 2);
+            packed[woff_r[i] + (j >> 4)] |= (uint32_t)cr << ((j & 15) * 2);
+        }
+    }
+    // ---- ordered pair list, row-major incl. self (seqrush.rs:718-734), sparsify, shard
+    c->pair_q.clear(); c->pair_t.clear(); c->dp_cells = 0;
+    uint64_t kept = 0;
+    for (uint32_t q = 0; q < n; q++)
+        for (uint32_t t = 0; t < n; t++) {
+            if (p->exclude_self && q == t) continue;
+            if (p->sparsify_kind == SR_SPARSE_RANDOM && q != t) {
+                const uint64_t h = splitmix64(p->sparsify_seed ^ ((uint64_t)q * n + t));
+                if ((double)(h >> 11) * (1.0 / 9007199254740992.0) >= p->sparsify_factor) continue;
+            }
+            if (kept % p->shard_count == p->shard_rank) {
+                c->pair_q.push_back(q); c->pair_t.push_back(t);
+                c->dp_cells += (uint64_t)c->len[q] * c->len[t];
+            }
+            kept++;
+        }
+    const uint32_t np = (uint32_t)c->pair_q.size();
+    c->cigar_base.assign((size_t)np + 1, 0);
+    std::vector<int32_t> max_score(np, INT_MAX);
+    for (uint32_t i = 0; i < np; i++) {
+        const uint64_t lq = c->len[c->pair_q[i]], lt = c->len[c->pair_t[i]];
+        c->cigar_base[i + 1] = c->cigar_base[i] + lq + lt + 2;
+        if (p->max_divergence >= 0.0) max_score[i] = max_score_for_divergence(*p, std::min(lq, lt), p->max_divergence);
+    }
+    // ---- geometry
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, c->device));
+    const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c->off16 = maxlen <= 32000 ? 1 : 0;
+    const size_t osz = c->off16 ? 2 : 4;
+    const uint32_t max_words = (uint32_t)((maxlen + 15) / 16 + 2);
+    c->lds_bytes = (size_t)max_words * 3 * 4;
+    if ((long long)c->lds_bytes > (long long)srk_align_max_lds())
+        return fail(SR_ERR_UNSUPPORTED, "sequences too long to stage in LDS (limit ~ 200 kb per sequence)");
+    int wg_per_cu = 4;
+    if (const char *e = getenv("SR_WG_PER_CU")) wg_per_cu = std::max(1, atoi(e));
+    const size_t lds_per_wg = c->lds_bytes + 16 * 1024;
+    wg_per_cu = (int)std::min<size_t>((size_t)wg_per_cu, std::max<size_t>(1, (160 * 1024) / lds_per_wg));
+    const int ring_scope = std::max(pen.scope, ori.scope);
+    const int ring_cap = (int)((2 * maxlen + 3 + 7) & ~7ULL);
+    const uint64_t ring_wg = 2ULL * ring_scope * 5 * (uint64_t)ring_cap;
+    const int gapmax = pen.two ? std::max(pen.o1, pen.o2) : pen.o1;
+    auto gc = [&](int len) { int g = pen.o1 + pen.e1 * len; if (pen.two) g = std::min(g, pen.o2 + pen.e2 * len); return g; };
+    const int smax_base = std::max(250 + gapmax, 2 * gc(100)) + 2 * gapmax + 4;
+    const int hist_levels = smax_base + 1;
+    int rmax = smax_base / pen.e1;
+    if (pen.two) rmax = std::max(rmax, smax_base / pen.e2);
+    const int hist_w = (2 * (rmax + pen.scope + 2) + 1 + 7) & ~7;
+    const uint64_t hist_wg = (uint64_t)hist_levels * 5 * (uint64_t)hist_w;
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    const uint64_t per_wg_bytes = (ring_wg + hist_wg) * osz;
+    uint64_t budget = (uint64_t)(free_b * 0.6);
+    int nwg = cus * wg_per_cu;
+    if ((uint64_t)nwg > np) nwg = (int)np;
+    if (nwg < 1) nwg = 1;
+    while (nwg > 1 && (uint64_t)nwg * per_wg_bytes > budget) nwg--;
+    if ((uint64_t)nwg * per_wg_bytes > budget) return fail(SR_ERR_NOMEM, "not enough device memory for one workgroup's wavefront ring");
+    c->nwg = nwg;
+    // ---- device buffers
+    SrAlignArgs &a = c->aa;
+    memset(&a, 0, sizeof(a));
+    void *d;
+#define DEV_UPLOAD(field, T, hostvec)                                                         \
+    do {                                                                                      \
+        if ((r = dev_alloc(c, &d, (hostvec).size() * sizeof(T)))) return r;                   \
+        HIPCHK(hipMemcpyAsync(d, (hostvec).data(), (hostvec).size() * sizeof(T), hipMemcpyHostToDevice, c->stream)); \
+        field = (T *)d;                                                                       \
+    } while (0)
+    uint32_t *d_words; uint64_t *d_wf, *d_wr, *d_goff, *d_cbase; uint32_t *d_len, *d_pq, *d_pt;
+    DEV_UPLOAD(d_words, uint32_t, packed);
+    DEV_UPLOAD(d_wf, uint64_t, woff_f);
+    DEV_UPLOAD(d_wr, uint64_t, woff_r);
+    DEV_UPLOAD(d_len, uint32_t, c->len);
+    DEV_UPLOAD(d_goff, uint64_t, c->goff);
+    std::vector<uint32_t> pq = c->pair_q, pt = c->pair_t;
+    if (pq.empty()) { pq.push_back(0); pt.push_back(0); }
+    DEV_UPLOAD(d_pq, uint32_t, pq);
+    DEV_UPLOAD(d_pt, uint32_t, pt);
+    DEV_UPLOAD(d_cbase, uint64_t, c->cigar_base);
+    DEV_UPLOAD(c->d_max_score, int32_t, max_score.empty() ? std::vector<int32_t>(1, INT_MAX) : max_score);
+    HIPCHK(hipStreamSynchronize(c->stream));   // host vectors go out of scope
+    if ((r = dev_alloc(c, &d, sizeof(uint32_t)))) return r; c->d_queue = (uint32_t *)d;
+    if ((r = dev_alloc(c, &d, (uint64_t)nwg * ring_wg * osz))) return r; a.ring = d;
+    if ((r = dev_alloc(c, &d, (uint64_t)nwg * hist_wg * osz))) return r; a.hist = d;
+    if ((r = dev_alloc(c, &d, (size_t)np + 1))) return r; a.is_reverse = (uint8_t *)d;
+    if ((r = dev_alloc(c, &d, ((size_t)np + 1) * 4))) return r; a.score = (int32_t *)d;
+    if ((r = dev_alloc(c, &d, ((size_t)np + 1) * 4))) return r; a.ori_fwd = (int32_t *)d;
+    if ((r = dev_alloc(c, &d, ((size_t)np + 1) * 4))) return r; a.ori_rev = (int32_t *)d;
+    if ((r = dev_alloc(c, &d, ((size_t)np + 1) * 4))) return r; a.cigar_cnt = (uint32_t *)d;
+    if ((r = dev_alloc(c, &d, (c->cigar_base[np] + 1) * 4))) return r; a.cigar_ops = (uint32_t *)d;
+    if ((r = dev_alloc(c, &d, 8 * sizeof(unsigned long long)))) return r; c->d_counters = (unsigned long long *)d;
+    if ((r = dev_alloc(c, &d, sizeof(int)))) return r; c->d_error = (int *)d;
+    if ((r = dev_alloc(c, &d, c->uf_size * 8))) return r; c->d_nodes = (unsigned long long *)d;
+    if ((r = dev_alloc(c, &d, c->uf_size * 8))) return r; c->d_minarr = (unsigned long long *)d;
+    if ((r = dev_alloc(c, &d, c->uf_size * 8))) return r; c->d_labels = (unsigned long long *)d;
+    HIPCHK(hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
+    HIPCHK(hipMemsetAsync(c->d_error, 0, sizeof(int), c->stream));
+    HIPCHK(hipMemsetAsync(a.cigar_cnt, 0, ((size_t)np + 1) * 4, c->stream));
+    HIPCHK(hipMemsetAsync(a.score, 0xff, ((size_t)np + 1) * 4, c->stream));
+    a.seqwords = d_words; a.word_off_fwd = d_wf; a.word_off_rc = d_wr; a.seqlen = d_len;
+    a.max_words = max_words; a.pair_q = d_pq; a.pair_t = d_pt; a.npairs = np;
+    a.queue_head = c->d_queue; a.pen = pen; a.ori = ori; a.mem_mode = p->memory_mode;
+    a.ring_wg_stride = ring_wg; a.ring_cap = ring_cap; a.ring_scope = ring_scope;
+    a.hist_wg_stride = hist_wg; a.hist_w = hist_w; a.hist_levels = hist_levels;
+    a.cigar_base = d_cbase; a.counters = c->d_counters; a.error_flag = c->d_error;
+    SrUniteArgs &u = c->ua;
+    memset(&u, 0, sizeof(u));
+    u.pair_q = d_pq; u.pair_t = d_pt; u.npairs = np; u.seqlen = d_len; u.seq_goff = d_goff;
+    u.is_reverse = a.is_reverse; u.score = a.score; u.max_score = c->d_max_score;
+    u.cigar_ops = a.cigar_ops; u.cigar_base = d_cbase; u.cigar_cnt = a.cigar_cnt;
+    u.min_match_len = p->min_match_len; u.nodes = c->d_nodes; u.uf_size = c->uf_size;
+    u.counters = c->d_counters; u.error_flag = c->d_error;
+    int rr = srk_uf_init(c->d_nodes, c->total_len, c->uf_size, c->stream);
+    if (rr) return fail(SR_ERR_HIP, "uf init launch failed");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->loaded = true;
+    return SR_OK;
+}
+
+extern "C" int sr_ctx_reset_uf(sr_ctx *c) {
+    if (!c || !c->loaded) return fail(SR_ERR_INVALID, "context not loaded");
+    HIPCHK(hipSetDevice(c->device));
+    if (srk_uf_init(c->d_nodes, c->total_len, c->uf_size, c->stream)) return fail(SR_ERR_HIP, "uf init launch failed");
+    return SR_OK;
+}
+
+extern "C" int sr_ctx_align(sr_ctx *c) {
+    if (!c || !c->loaded) return fail(SR_ERR_INVALID, "context not loaded");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemsetAsync(c->d_queue, 0, sizeof(uint32_t), c->stream));
+    HIPCHK(hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
+    HIPCHK(hipEventRecord(c->ev[0][0], c->stream));
+    if (c->aa.npairs > 0) {
+        int r = srk_align(&c->aa, c->nwg, c->lds_bytes, c->off16, c->stream);
+        if (r) return fail(SR_ERR_HIP, std::string("align kernel launch failed: ") + hipGetErrorString((hipError_t)r));
+    }
+    HIPCHK(hipEventRecord(c->ev[0][1], c->stream));
+    c->ev_valid[0] = true;
+    return SR_OK;
+}
+
+extern "C" int sr_ctx_unite(sr_ctx *c) {
+    if (!c || !c->loaded) return fail(SR_ERR_INVALID, "context not loaded");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipEventRecord(c->ev[1][0], c->stream));
+    if (c->ua.npairs > 0) {
+        int nwg = (int)std::min<uint64_t>(c->ua.npairs, 4096);
+        int r = srk_unite(&c->ua, nwg, c->stream);
+        if (r) return fail(SR_ERR_HIP, std::string("unite kernel launch failed: ") + hipGetErrorString((hipError_t)r));
+    }
+    HIPCHK(hipEventRecord(c->ev[1][1], c->stream));
+    c->ev_valid[1] = true;
+    return SR_OK;
+}
+
+extern "C" int sr_ctx_sync(sr_ctx *c) {
+    if (!c) return fail(SR_ERR_INVALID, "null ctx");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->loaded) {
+        int err = 0;
+        HIPCHK(hipMemcpy(&err, c->d_error, sizeof(int), hipMemcpyDeviceToHost));
+        if (err) {
+            char buf[128];
+            snprintf(buf, sizeof(buf), "device reported internal fault bits 0x%x", err);
+            return fail(SR_ERR_DEVICE_FAULT, buf);
+        }
+    }
+    return SR_OK;
+}
+
+extern "C" uint64_t sr_ctx_uf_size(const sr_ctx *c) { return c ? c->uf_size : 0; }
+extern "C" uint64_t sr_ctx_num_pairs(const sr_ctx *c) { return c ? c->pair_q.size() : 0; }
+extern "C" uint64_t sr_ctx_dp_cells(const sr_ctx *c) { return c ? c->dp_cells : 0; }
+
+extern "C" int sr_ctx_kernel_ms(sr_ctx *c, int which, float *ms) {
+    if (!c || which < 0 || which > 2 || !c->ev_valid[which]) return fail(SR_ERR_INVALID, "no timing recorded");
+    HIPCHK(hipEventSynchronize(c->ev[which][1]));
+    HIPCHK(hipEventElapsedTime(ms, c->ev[which][0], c->ev[which][1]));
+    return SR_OK;
+}
+
+extern "C" int sr_ctx_counters(sr_ctx *c, uint64_t out[8]) {
+    if (!c || !c->loaded) return fail(SR_ERR_INVALID, "context not loaded");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, c->d_counters, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+
+extern "C" int sr_ctx_download_uf(sr_ctx *c, uint64_t *parent_out) {
+    if (!c || !c->loaded) return fail(SR_ERR_INVALID, "context not loaded");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(parent_out, c->d_nodes, c->uf_size * 8, hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+
+extern "C" int sr_ctx_labels_device(sr_ctx *c, uint64_t *dev_labels) {
+    if (!c || !c->loaded) return fail(SR_ERR_INVALID, "context not loaded");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipEventRecord(c->ev[2][0], c->stream));
+    if (srk_labels(c->d_nodes, c->uf_size, c->d_minarr, (unsigned long long *)dev_labels, c->d_error, c->stream))
+        return fail(SR_ERR_HIP, "label kernel launch failed");
+    HIPCHK(hipEventRecord(c->ev[2][1], c->stream));
+    c->ev_valid[2] = true;
+    return SR_OK;
+}
+
+extern "C" int sr_ctx_merge_labels(sr_ctx *c, const uint64_t *dev_labels, uint32_t count) {
+    if (!c || !c->loaded) return fail(SR_ERR_INVALID, "context not loaded");
+    HIPCHK(hipSetDevice(c->device));
+    if (srk_merge(c->d_nodes, c->uf_size, (const unsigned long long *)dev_labels, count, c->d_error, c->stream))
+        return fail(SR_ERR_HIP, "merge kernel launch failed");
+    return SR_OK;
+}
+
+extern "C" int sr_ctx_download_labels(sr_ctx *c, uint64_t *labels_out) {
+    int r = sr_ctx_labels_device(c, (uint64_t *)c->d_labels);
+    if (r) return r;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(labels_out, c->d_labels, c->uf_size * 8, hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+
+// ------------------------------------------------------------------ results
+extern "C" void sr_alignments_free(sr_alignments *a) {
+    if (!a) return;
+    free(a->query_idx); free(a->target_idx); free(a->is_reverse); free(a->score);
+    free(a->query_start); free(a->query_end); free(a->target_start); free(a->target_end);
+    free(a->cigar_off); free(a->cigar_ops);
+    free(a);
+}
+
+extern "C" int sr_ctx_alignments(sr_ctx *c, sr_alignments **out) {
+    if (!c || !c->loaded) return fail(SR_ERR_INVALID, "context not loaded");
+    int r = sr_ctx_sync(c);
+    if (r) return r;
+    const size_t np = c->pair_q.size();
+    std::vector<uint32_t> cnt(np + 1), ops(c->cigar_base[np] + 1);
+    std::vector<int32_t> score(np + 1);
+    std::vector<uint8_t> isrev(np + 1);
+    HIPCHK(hipMemcpy(cnt.data(), c->aa.cigar_cnt, (np + 1) * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(score.data(), c->aa.score, (np + 1) * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(isrev.data(), c->aa.is_reverse, np + 1, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ops.data(), c->aa.cigar_ops, (c->cigar_base[np] + 1) * 4, hipMemcpyDeviceToHost));
+    sr_alignments *a = (sr_alignments *)calloc(1, sizeof(sr_alignments));
+    a->n = np;
+    const size_t m = np ? np : 1;
+    a->query_idx = (uint32_t *)malloc(m * 4); a->target_idx = (uint32_t *)malloc(m * 4);
+    a->is_reverse = (uint8_t *)malloc(m); a->score = (int32_t *)malloc(m * 4);
+    a->query_start = (uint64_t *)malloc(m * 8); a->query_end = (uint64_t *)malloc(m * 8);
+    a->target_start = (uint64_t *)malloc(m * 8); a->target_end = (uint64_t *)malloc(m * 8);
+    a->cigar_off = (uint64_t *)malloc((np + 1) * 8);
+    uint64_t tot = 0;
+    for (size_t i = 0; i < np; i++) tot += cnt[i];
+    a->cigar_ops = (uint32_t *)malloc((tot ? tot : 1) * 4);
+    uint64_t w = 0;
+    for (size_t i = 0; i < np; i++) {
+        a->query_idx[i] = c->pair_q[i]; a->target_idx[i] = c->pair_t[i];
+        a->is_reverse[i] = isrev[i]; a->score[i] = score[i];
+        a->query_start[i] = 0; a->query_end[i] = c->len[c->pair_q[i]];     // allwave aligns full sequences (seqrush.rs:743-753)
+        a->target_start[i] = 0; a->target_end[i] = c->len[c->pair_t[i]];
+        a->cigar_off[i] = w;
+        const uint32_t *src = ops.data() + c->cigar_base[i];
+        for (uint32_t j = 0; j < cnt[i]; j++) {
+            uint32_t op = src[j] & 15u, len = src[j] >> 4;
+            // raw WFA2 alphabet -> reference alphabet (src/wfa.rs:25-31): M->'=', I<->D swapped
+            uint32_t o2 = op == SR_OP_M ? 0u : op == SR_OP_X ? 1u : op == SR_OP_I ? 3u : 2u;
+            a->cigar_ops[w++] = (len << 4) | o2;
+        }
+    }
+    a->cigar_off[np] = w;
+    *out = a;
+    return SR_OK;
+}
+
+extern "C" size_t sr_alignment_cigar(const sr_alignments *a, uint64_t i, char *buf, size_t cap) {
+    static const char opc[4] = {'=', 'X', 'I', 'D'};
+    size_t need = 0;
+    if (!a || i >= a->n) return 0;
+    for (uint64_t j = a->cigar_off[i]; j < a->cigar_off[i + 1]; j++) {
+        char tmp[24];
+        int l = snprintf(tmp, sizeof(tmp), "%u%c", a->cigar_ops[j] >> 4, opc[a->cigar_ops[j] & 3u]);
+        if (buf && need + (size_t)l < cap) memcpy(buf + need, tmp, (size_t)l);
+        need += (size_t)l;
+    }
+    if (buf && cap) buf[std::min(need, cap - 1)] = 0;
+    return need;
+}
+
+extern "C" int sr_align_all(const sr_seqset *seqs, const sr_params *p, sr_alignments **out) {
+    if (!seqs || !p || !out) return fail(SR_ERR_INVALID, "null argument");
+    sr_ctx *c = nullptr;
+    int r = sr_ctx_create(p->device, &c);
+    if (r) return r;
+    if (!(r = sr_ctx_load(c, seqs, p)) && !(r = sr_ctx_align(c))) r = sr_ctx_alignments(c, out);
+    std::string keep = g_err;
+    sr_ctx_destroy(c);
+    g_err = keep;
+    return r;
+}
+
+extern "C" int sr_align_and_unite(const sr_seqset *seqs, const sr_params *p, uint64_t *parent_out) {
+    if (!seqs || !p || !parent_out) return fail(SR_ERR_INVALID, "null argument");
+    sr_ctx *c = nullptr;
+    int r = sr_ctx_create(p->device, &c);
+    if (r) return r;
+    if (!(r = sr_ctx_load(c, seqs, p)) && !(r = sr_ctx_align(c)) && !(r = sr_ctx_unite(c)) && !(r = sr_ctx_sync(c))) {
+        if (p->canonical_labels) r = sr_ctx_download_labels(c, parent_out);
+        else r = sr_ctx_download_uf(c, parent_out);
+        if (!r) r = sr_ctx_sync(c);
+    }
+    std::string keep = g_err;
+    sr_ctx_destroy(c);
+    g_err = keep;
+    return r;
+}
+
+// UFRush::find (read-only walk) / same, uf_rush lib.rs:112-133, 72-84
+extern "C" uint64_t sr_uf_find(const uint64_t *nodes, uint64_t n, uint64_t x) {
+    const uint64_t mask = 0x03FFFFFFFFFFFFFFULL;
+    if (x >= n) return UINT64_MAX;
+    uint64_t guard = 0;
+    while ((nodes[x] & mask) != x && guard++ < n) x = nodes[x] & mask;
+    return x;
+}
+extern "C" int sr_uf_same(const uint64_t *nodes, uint64_t n, uint64_t x, uint64_t y) {
+    return sr_uf_find(nodes, n, x) == sr_uf_find(nodes, n, y);
+}
+
+// ------------------------------------------------------------------ PAF (seam 3)
+extern "C" int sr_write_paf(const sr_alignments *a, const sr_seqset *seqs, const char *path) {
+    if (!a || !seqs || !path || !seqs->names) return fail(SR_ERR_INVALID, "null argument");
+    FILE *f = fopen(path, "w");
+    if (!f) return fail(SR_ERR_IO, std::string("cannot open ") + path);
+    std::vector<char> buf;
+    for (uint64_t i = 0; i < a->n; i++) {
+        const uint32_t q = a->query_idx[i], t = a->target_idx[i];
+        uint64_t matches = 0, alen = 0;
+        for (uint64_t j = a->cigar_off[i]; j < a->cigar_off[i + 1]; j++) {
+            const uint32_t len = a->cigar_ops[j] >> 4;
+            if ((a->cigar_ops[j] & 3u) == 0) matches += len;
+            alen += len;
+        }
+        const size_t need = sr_alignment_cigar(a, i, nullptr, 0);
+        buf.resize(need + 1);
+        sr_alignment_cigar(a, i, buf.data(), need + 1);
+        // 12 mandatory PAF columns + cg:Z: (parsed by seqrush.rs:536-559)
+        fprintf(f, "%s\t%llu\t%llu\t%llu\t%c\t%s\t%llu\t%llu\t%llu\t%llu\t%llu\t255\tAS:i:%d\tcg:Z:%s\n",
+                seqs->names[q], (unsigned long long)(seqs->offsets[q + 1] - seqs->offsets[q]),
+                (unsigned long long)a->query_start[i], (unsigned long long)a->query_end[i],
+                a->is_reverse[i] ? '-' : '+', seqs->names[t],
+                (unsigned long long)(seqs->offsets[t + 1] - seqs->offsets[t]),
+                (unsigned long long)a->target_start[i], (unsigned long long)a->target_end[i],
+                (unsigned long long)matches, (unsigned long long)alen, a->score[i], buf.data());
+    }
+    fclose(f);
+    return SR_OK;
+}
+
+// ------------------------------------------------------------------ GFA (A9)
+// O(N) formulation of build_bidirected_graph_with_options
+// (bidirected_builder.rs:17-289) for a quiescent UF given as canonical labels:
+// node ids in first-encounter order over sequences / positions (:29-41,
+// :154-157), node base = base at offset(label) (:176-182), step reversed iff
+// node base and sequence base are complementary (:190-203), edges deduplicated
+// against themselves and their complement, first orientation kept
+// (bidirected_ops.rs:813-825); write_gfa layout bidirected_ops.rs:880-925.
+struct PairHash {
+    size_t operator()(const std::pair<uint64_t, uint64_t> &p) const {
+        return (size_t)splitmix64(p.first * 0x9e3779b97f4a7c15ULL ^ p.second);
+    }
+};
+
+extern "C" int sr_build_gfa(const sr_seqset *seqs, const uint64_t *labels, char **gfa,
+                            uint64_t *n_nodes, uint64_t *n_edges) {
+    if (!seqs || !labels || !gfa || !seqs->names) return fail(SR_ERR_INVALID, "null argument");
+    const uint64_t N = seqs->offsets[seqs->n];
+    const uint64_t ufn = 2 * N + 2;
+    std::vector<uint64_t> node_of(ufn, 0);
+    std::vector<uint8_t> node_base(1, 0);
+    std::vector<uint64_t> steps(N);
+    uint64_t next_id = 1;
+    for (uint32_t s = 0; s < seqs->n; s++) {
+        for (uint64_t g = seqs->offsets[s]; g < seqs->offsets[s + 1]; g++) {
+            const uint64_t lf = labels[g << 1], lr = labels[(g << 1) | 1];
+            if (lf >= ufn || lr >= ufn) return fail(SR_ERR_INVALID, "label out of range");
+            uint64_t rep = node_of[lf] ? lf : (node_of[lr] ? lr : lf);
+            uint64_t id = node_of[rep];
+            if (!id) {
+                id = next_id++;
+                node_of[rep] = id;
+                const uint64_t off = rep >> 1;
+                node_base.push_back(off < N ? seqs->bases[off] : seqs->bases[g]);
+            }
+            const uint8_t nb = (uint8_t)toupper(node_base[id]), eb = (uint8_t)toupper(seqs->bases[g]);
+            const bool rev = (nb == 'A' && eb == 'T') || (nb == 'T' && eb == 'A') ||
+                             (nb == 'C' && eb == 'G') || (nb == 'G' && eb == 'C');
+            steps[g] = (id << 1) | (rev ? 1 : 0);
+        }
+    }
+    std::unordered_set<std::pair<uint64_t, uint64_t>, PairHash> eset;
+    std::vector<std::pair<uint64_t, uint64_t>> eorder;
+    eset.reserve(N);
+    for (uint32_t s = 0; s < seqs->n; s++)
+        for (uint64_t g = seqs->offsets[s]; g + 1 < seqs->offsets[s + 1]; g++) {
+            const uint64_t from = steps[g], to = steps[g + 1];
+            if (eset.count({from, to}) || eset.count({to ^ 1, from ^ 1})) continue;
+            eset.insert({from, to});
+            eorder.push_back({from, to});
+        }
+    std::string out;
+    out.reserve(N * 8 + 64);
+    out += "H\tVN:Z:1.0\n";
+    char tmp[96];
+    for (uint64_t id = 1; id < next_id; id++) {
+        snprintf(tmp, sizeof(tmp), "S\t%llu\t%c\n", (unsigned long long)id, (char)node_base[id]);
+        out += tmp;
+    }
+    for (auto &e : eorder) {
+        snprintf(tmp, sizeof(tmp), "L\t%llu\t%c\t%llu\t%c\t0M\n", (unsigned long long)(e.first >> 1),
+                 (e.first & 1) ? '-' : '+', (unsigned long long)(e.second >> 1), (e.second & 1) ? '-' : '+');
+        out += tmp;
+    }
+    for (uint32_t s = 0; s < seqs->n; s++) {
+        out += "P\t"; out += seqs->names[s]; out += "\t";
+        for (uint64_t g = seqs->offsets[s]; g < seqs->offsets[s + 1]; g++) {
+            if (g != seqs->offsets[s]) out += ',';
+            snprintf(tmp, sizeof(tmp), "%llu%c", (unsigned long long)(steps[g] >> 1), (steps[g] & 1) ? '-' : '+');
+            out += tmp;
+        }
+        out += "\t*\n";
+    }
+    char *res = (char *)malloc(out.size() + 1);
+    memcpy(res, out.c_str(), out.size() + 1);
+    *gfa = res;
+    if (n_nodes) *n_nodes = next_id - 1;
+    if (n_edges) *n_edges = eorder.size();
+    return SR_OK;
+}

@@ -1,0 +1,98 @@
+// Internal structs shared by the HIP kernels (sr_device.hip) and the host side
+// of the C ABI (sr_host.cpp).  Not part of the public interface.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#define SR_NULL_OFF (-8192)          // null wavefront offset (fits int16)
+#define SR_MAX_SCOPE 128             // max ring depth supported on device
+#define SR_STACK_DEPTH 64
+#define SR_WG 256                    // threads per workgroup (4 waves of 64)
+
+enum { SR_C_M = 0, SR_C_I1 = 1, SR_C_I2 = 2, SR_C_D1 = 3, SR_C_D2 = 4 };
+// raw WFA2 op codes used in device CIGAR ops: (len << 4) | op
+enum { SR_OP_M = 0, SR_OP_X = 1, SR_OP_I = 2 /* consumes text */, SR_OP_D = 3 /* consumes pattern */ };
+
+// device error bits (per launch, OR-ed into *error_flag)
+enum {
+    SR_DEV_ERR_SCORE_BOUND = 1,   // score loop exceeded its safety bound
+    SR_DEV_ERR_BASE_OVERFLOW = 2, // base-case WFA exceeded the history depth
+    SR_DEV_ERR_BACKTRACE = 4,     // backtrace found no predecessor
+    SR_DEV_ERR_STACK = 8,         // biWFA recursion stack overflow
+    SR_DEV_ERR_CIGAR_OVERFLOW = 16,
+    SR_DEV_ERR_UF_SPIN = 32,      // union-find retry bound hit
+    SR_DEV_ERR_BREAKPOINT = 64    // breakpoint outside the segment
+};
+
+struct SrPen {
+    int x, o1, e1, o2, e2;
+    int two;      // 1 = gap-affine-2p
+    int scope;    // max(x, o1+e1, o2+e2) + 1
+};
+
+struct SrAlignArgs {
+    // packed sequences: 2 bits/base, 16 bases per word, every sequence copy is
+    // framed by one pad word on each side
+    const uint32_t *seqwords;
+    const uint64_t *word_off_fwd;   // [n] index of the first real word
+    const uint64_t *word_off_rc;    // [n] same for the reverse complement
+    const uint32_t *seqlen;         // [n]
+    uint32_t max_words;             // words per LDS region (incl. pads)
+    // pair list (this rank's shard)
+    const uint32_t *pair_q, *pair_t;
+    uint32_t npairs;
+    uint32_t *queue_head;
+    SrPen pen, ori;
+    int mem_mode;
+    // per-workgroup workspace
+    void *ring;                // [nwg][2][scope_max][5][ring_cap] offsets
+    uint64_t ring_wg_stride;   // elements per workgroup
+    int ring_cap;
+    int ring_scope;            // slots allocated per direction
+    void *hist;                // [nwg][hist_levels][5][hist_w]
+    uint64_t hist_wg_stride;
+    int hist_w, hist_levels;
+    // outputs
+    uint8_t *is_reverse;       // [npairs]
+    int32_t *score;            // [npairs]
+    int32_t *ori_fwd, *ori_rev;// [npairs] orientation scores (rev = INT_MAX if not better)
+    uint32_t *cigar_ops;
+    const uint64_t *cigar_base;// [npairs+1]
+    uint32_t *cigar_cnt;       // [npairs]
+    unsigned long long *counters; // [8]
+    int *error_flag;
+};
+
+struct SrUniteArgs {
+    const uint32_t *pair_q, *pair_t;
+    uint32_t npairs;
+    const uint32_t *seqlen;
+    const uint64_t *seq_goff;       // [n] global offsets (concatenated coordinates)
+    const uint8_t *is_reverse;
+    const int32_t *score;
+    const int32_t *max_score;       // [npairs] divergence filter bound or INT_MAX
+    const uint32_t *cigar_ops;
+    const uint64_t *cigar_base;
+    const uint32_t *cigar_cnt;
+    uint64_t min_match_len;
+    unsigned long long *nodes;      // uf_rush node array
+    uint64_t uf_size;
+    unsigned long long *counters;
+    int *error_flag;
+};
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+// launchers implemented in sr_device.hip (hipStream_t passed as void*)
+int srk_align(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, void *stream);
+int srk_unite(const SrUniteArgs *a, int nwg, void *stream);
+int srk_uf_init(unsigned long long *nodes, uint64_t total_len, uint64_t uf_size, void *stream);
+int srk_labels(unsigned long long *nodes, uint64_t uf_size, unsigned long long *minarr,
+               unsigned long long *labels, int *error_flag, void *stream);
+int srk_merge(unsigned long long *nodes, uint64_t uf_size, const unsigned long long *labels,
+              uint32_t count, int *error_flag, void *stream);
+int srk_align_max_lds(void);
+#ifdef __cplusplus
+}
+#endif

@@ -1,0 +1,393 @@
+"""Host-side mirror of the reference's production entry points for the hot path.
+
+Reference (pangenome/seqrush): ``Args`` src/seqrush.rs:17-152, ``Sequence``
+:272-277, ``load_sequences`` :1801-1837, ``SeqRush::new`` :308-336,
+``build_graph`` :433-458, ``align_and_unite_with_allwave`` :611-757,
+``run_seqrush`` :1839-1853.  Everything that computes calls the C ABI
+(``include/seqrush_amd.h``); there is no Python or CPU alignment path.
+"""
+import ctypes as C
+import dataclasses
+from typing import List, Optional, Sequence as Seq
+
+import numpy as np
+
+from . import _lib
+from ._lib import ParamsC, SeqSetC, AlignmentsC, check, SeqRushError
+
+SR_MEM_HIGH, SR_MEM_ULTRALOW = 0, 3
+
+
+# --------------------------------------------------------------------------- args
+@dataclasses.dataclass
+class Args:
+    """Flag surface of the reference CLI that the hot path reads (src/seqrush.rs:17-152)."""
+    sequences: str = ""                     # -s
+    output: str = "output.gfa"              # -o
+    min_match_length: int = 0               # -k
+    threads: int = 4                        # -t (host threads; the device path ignores it)
+    scores: str = "0,5,8,2,24,1"            # -S
+    orientation_scores: str = "0,1,1,1"     # --orientation-scores
+    max_divergence: Optional[float] = None  # -d
+    sparsification: str = "none"            # -x
+    paf: Optional[str] = None               # -p (not implemented: seam 3 input)
+    output_alignments: Optional[str] = None  # --output-alignments
+    no_compact: bool = True                 # only --no-compact is implemented
+    no_sort: bool = True                    # only --no-sort is implemented
+    aligner: str = "allwave"
+    verbose: bool = False
+    device: int = 0                         # added: HIP device ordinal
+    shard_rank: int = 0                     # added: multi-GPU pair shard
+    shard_count: int = 1
+
+
+@dataclasses.dataclass
+class AlignmentScores:
+    """src/seqrush.rs:154-250"""
+    match_score: int
+    mismatch_penalty: int
+    gap1_open: int
+    gap1_extend: int
+    gap2_open: Optional[int] = None
+    gap2_extend: Optional[int] = None
+
+    @staticmethod
+    def parse(scores_str: str) -> "AlignmentScores":
+        p = ParamsC()
+        L = _lib.load()
+        L.sr_default_params(C.byref(p))
+        check(L.sr_parse_scores(scores_str.encode(), C.byref(p)))
+        two = p.gap_open2 >= 0
+        return AlignmentScores(p.match_score, p.mismatch_penalty, p.gap_open1, p.gap_ext1,
+                               p.gap_open2 if two else None, p.gap_ext2 if two else None)
+
+    @staticmethod
+    def parse_orientation(scores_str: str) -> "AlignmentScores":
+        p = ParamsC()
+        L = _lib.load()
+        L.sr_default_params(C.byref(p))
+        check(L.sr_parse_orientation_scores(scores_str.encode(), C.byref(p)))
+        return AlignmentScores(p.ori_match, p.ori_mismatch, p.ori_gap_open, p.ori_gap_ext)
+
+
+@dataclasses.dataclass
+class Sequence:
+    """src/seqrush.rs:272-277"""
+    id: str
+    data: bytes
+    offset: int = 0
+
+
+def load_sequences(file_path: str) -> List[Sequence]:
+    """FASTA loader with the reference's exact record rules (src/seqrush.rs:1801-1837):
+    id = first whitespace token after '>', lines trimmed and concatenated verbatim,
+    offset = running sum, records with an empty id are dropped."""
+    sequences: List[Sequence] = []
+    current_id = ""
+    current = bytearray()
+    offset = 0
+    with open(file_path, "rb") as fh:
+        text = fh.read()
+    lines = text.split(b"\n")
+    if lines and lines[-1] == b"":
+        lines.pop()
+    ws = b" \t\n\r\x0b\x0c"
+    for line in lines:
+        if line.endswith(b"\r"):
+            line = line[:-1]
+        if line.startswith(b">"):
+            if current_id:
+                sequences.append(Sequence(current_id, bytes(current), offset))
+                offset += len(current)
+                current = bytearray()
+            toks = line[1:].split()
+            current_id = toks[0].decode() if toks else ""
+        else:
+            current.extend(line.strip(ws))
+    if current_id:
+        sequences.append(Sequence(current_id, bytes(current), offset))
+    return sequences
+
+
+# --------------------------------------------------------------------------- C ABI wrappers
+class SeqSet:
+    """Owns the buffers behind an ``sr_seqset``."""
+
+    def __init__(self, records: Seq):
+        """records: iterable of (name, bytes) or Sequence"""
+        names, datas = [], []
+        for r in records:
+            if isinstance(r, Sequence):
+                names.append(r.id); datas.append(bytes(r.data))
+            else:
+                names.append(r[0]); datas.append(bytes(r[1]))
+        self.names = names
+        self.lengths = [len(d) for d in datas]
+        self._bases = b"".join(datas)
+        self._offsets = np.zeros(len(datas) + 1, dtype=np.uint64)
+        np.cumsum(self.lengths, out=self._offsets[1:])
+        self._names_c = (C.c_char_p * max(1, len(names)))(*[n.encode() for n in names])
+        self.c = SeqSetC(len(datas), self._bases, self._offsets.ctypes.data_as(C.POINTER(C.c_uint64)),
+                         C.cast(self._names_c, C.POINTER(C.c_char_p)))
+
+    @property
+    def n(self):
+        return len(self.names)
+
+    @property
+    def total_length(self):
+        return int(self._offsets[-1])
+
+    def offset(self, i):
+        return int(self._offsets[i])
+
+    def seq(self, i):
+        return self._bases[int(self._offsets[i]): int(self._offsets[i + 1])]
+
+
+class Params:
+    """``sr_params`` with the reference defaults (src/seqrush.rs:33-75)."""
+
+    def __init__(self, **kw):
+        self.c = ParamsC()
+        _lib.load().sr_default_params(C.byref(self.c))
+        for k, v in kw.items():
+            self.set(k, v)
+
+    def set(self, k, v):
+        if k == "scores":
+            check(_lib.load().sr_parse_scores(v.encode(), C.byref(self.c)))
+        elif k == "orientation_scores":
+            check(_lib.load().sr_parse_orientation_scores(v.encode(), C.byref(self.c)))
+        elif k == "sparsification":
+            check(_lib.load().sr_parse_sparsification(v.encode(), C.byref(self.c)))
+        elif k == "max_divergence":
+            self.c.max_divergence = -1.0 if v is None else float(v)
+        else:
+            if not hasattr(self.c, k):
+                raise AttributeError(k)
+            setattr(self.c, k, v)
+
+    @staticmethod
+    def from_args(args: Args) -> "Params":
+        p = Params(scores=args.scores, orientation_scores=args.orientation_scores,
+                   sparsification=args.sparsification, max_divergence=args.max_divergence)
+        p.c.min_match_len = args.min_match_length
+        p.c.device = args.device
+        p.c.shard_rank, p.c.shard_count = args.shard_rank, args.shard_count
+        return p
+
+
+class Alignments:
+    """Owned ``sr_alignments`` (Seam 1 result)."""
+
+    def __init__(self, ptr):
+        self._p = ptr
+        a = ptr.contents
+        n = int(a.n)
+        self.n = n
+
+        def arr(p, dt, m):
+            return np.ctypeslib.as_array(p, shape=(max(m, 1),))[:m].astype(dt, copy=True)
+        self.query_idx = arr(a.query_idx, np.uint32, n)
+        self.target_idx = arr(a.target_idx, np.uint32, n)
+        self.is_reverse = arr(a.is_reverse, np.uint8, n)
+        self.score = arr(a.score, np.int32, n)
+        self.query_start = arr(a.query_start, np.uint64, n)
+        self.query_end = arr(a.query_end, np.uint64, n)
+        self.target_start = arr(a.target_start, np.uint64, n)
+        self.target_end = arr(a.target_end, np.uint64, n)
+        self.cigar_off = arr(a.cigar_off, np.uint64, n + 1)
+        self.cigar_ops = arr(a.cigar_ops, np.uint32, int(self.cigar_off[-1]) if n else 0)
+
+    def cigar(self, i: int) -> str:
+        ops = self.cigar_ops[int(self.cigar_off[i]): int(self.cigar_off[i + 1])]
+        return "".join(f"{int(o) >> 4}{'=XID'[int(o) & 3]}" for o in ops)
+
+    def raw_cigar_bytes(self, i: int) -> bytes:
+        """per-column raw WFA2 alphabet (M X I D), i.e. allwave's ``cigar_bytes``"""
+        ops = self.cigar_ops[int(self.cigar_off[i]): int(self.cigar_off[i + 1])]
+        tr = {0: b"M", 1: b"X", 2: b"D", 3: b"I"}   # undo the I<->D swap of src/wfa.rs:25-31
+        return b"".join(tr[int(o) & 3] * (int(o) >> 4) for o in ops)
+
+    def write_paf(self, seqset: SeqSet, path: str):
+        check(_lib.load().sr_write_paf(self._p, C.byref(seqset.c), path.encode()))
+
+    def close(self):
+        if self._p:
+            _lib.load().sr_alignments_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Context:
+    """Resident device context (``sr_ctx``): what ``bench.py`` times."""
+
+    def __init__(self, device: int = 0):
+        self.L = _lib.load()
+        self._h = C.c_void_p()
+        check(self.L.sr_ctx_create(device, C.byref(self._h)))
+        self.seqset = None
+
+    def set_stream(self, stream_ptr: int):
+        check(self.L.sr_ctx_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def load(self, seqset: SeqSet, params: Params):
+        self.seqset = seqset
+        check(self.L.sr_ctx_load(self._h, C.byref(seqset.c), C.byref(params.c)))
+
+    def reset_uf(self):
+        check(self.L.sr_ctx_reset_uf(self._h))
+
+    def align(self):
+        check(self.L.sr_ctx_align(self._h))
+
+    def unite(self):
+        check(self.L.sr_ctx_unite(self._h))
+
+    def sync(self):
+        check(self.L.sr_ctx_sync(self._h))
+
+    def alignments(self) -> Alignments:
+        p = C.POINTER(AlignmentsC)()
+        check(self.L.sr_ctx_alignments(self._h, C.byref(p)))
+        return Alignments(p)
+
+    @property
+    def uf_size(self):
+        return int(self.L.sr_ctx_uf_size(self._h))
+
+    @property
+    def num_pairs(self):
+        return int(self.L.sr_ctx_num_pairs(self._h))
+
+    @property
+    def dp_cells(self):
+        return int(self.L.sr_ctx_dp_cells(self._h))
+
+    def download_uf(self) -> np.ndarray:
+        out = np.zeros(self.uf_size, dtype=np.uint64)
+        check(self.L.sr_ctx_download_uf(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return out
+
+    def download_labels(self) -> np.ndarray:
+        out = np.zeros(self.uf_size, dtype=np.uint64)
+        check(self.L.sr_ctx_download_labels(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return out
+
+    def labels_device(self, dev_ptr: int):
+        check(self.L.sr_ctx_labels_device(self._h, C.c_void_p(dev_ptr)))
+
+    def merge_labels(self, dev_ptr: int, count: int):
+        check(self.L.sr_ctx_merge_labels(self._h, C.c_void_p(dev_ptr), count))
+
+    def kernel_ms(self, which: int) -> float:
+        ms = C.c_float()
+        check(self.L.sr_ctx_kernel_ms(self._h, which, C.byref(ms)))
+        return float(ms.value)
+
+    def counters(self):
+        out = (C.c_uint64 * 8)()
+        check(self.L.sr_ctx_counters(self._h, out))
+        return dict(wf_cells=int(out[0]), wf_steps=int(out[1]), base_segments=int(out[2]),
+                    breakpoint_searches=int(out[3]), united_bases=int(out[4]), match_runs=int(out[5]))
+
+    def close(self):
+        if self._h:
+            self.L.sr_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def build_gfa(seqset: SeqSet, labels: np.ndarray):
+    """Graph induction + GFA text from canonical labels (consumer A9; --no-sort --no-compact).
+    -> (gfa_text, n_nodes, n_edges)"""
+    L = _lib.load()
+    labels = np.ascontiguousarray(labels, dtype=np.uint64)
+    out = C.c_void_p(); nn = C.c_uint64(); ne = C.c_uint64()
+    check(L.sr_build_gfa(C.byref(seqset.c), labels.ctypes.data_as(C.POINTER(C.c_uint64)),
+                         C.byref(out), C.byref(nn), C.byref(ne)))
+    text = C.cast(out, C.c_char_p).value.decode()
+    L.sr_free(out)
+    return text, int(nn.value), int(ne.value)
+
+
+def uf_find(nodes: np.ndarray, x: int) -> int:
+    nodes = np.ascontiguousarray(nodes, dtype=np.uint64)
+    return int(_lib.load().sr_uf_find(nodes.ctypes.data_as(C.POINTER(C.c_uint64)), len(nodes), x))
+
+
+# --------------------------------------------------------------------------- SeqRush
+class SeqRush:
+    """Mirror of ``SeqRush`` (src/seqrush.rs:298-336, 433-458) over the device path."""
+
+    def __init__(self, sequences: List[Sequence], device: int = 0):
+        for s in sequences:                                  # :310-317
+            if len(s.data) == 0:
+                raise ValueError(
+                    f"Empty sequences are not allowed: sequence '{s.id}' has length 0")
+        off = 0
+        for s in sequences:
+            s.offset = off
+            off += len(s.data)
+        self.sequences = sequences
+        self.total_length = off
+        self.seqset = SeqSet(sequences)
+        self.ctx = Context(device)
+        self.labels = None
+        self.alignments = None
+
+    def align_and_unite(self, args: Args):
+        """align_and_unite_with_allwave (src/seqrush.rs:611-757) on the device"""
+        if args.paf is not None:
+            raise SeqRushError(-6, "-p/--paf input is not implemented (SURVEY 8f rank 4)")
+        if args.aligner.lower() != "allwave":
+            raise SeqRushError(-6, f"aligner '{args.aligner}' is out of scope; only 'allwave'")
+        params = Params.from_args(args)
+        self.ctx.load(self.seqset, params)
+        n = len(self.sequences)
+        print(f"Total sequence pairs: {n * n} (sparsification: {args.sparsification})")
+        self.ctx.align()
+        self.ctx.unite()
+        self.ctx.sync()
+        if args.output_alignments:
+            al = self.ctx.alignments()
+            print(f"Writing alignments to {args.output_alignments}")
+            al.write_paf(self.seqset, args.output_alignments)
+            al.close()
+        self.labels = self.ctx.download_labels()
+        self.ctx.sync()
+
+    def build_graph(self, args: Args):
+        print(f"Building graph with {len(self.sequences)} sequences "
+              f"(total length: {self.total_length})")
+        self.align_and_unite(args)
+        self.write_gfa(args)
+
+    def write_gfa(self, args: Args):
+        if not (args.no_sort and args.no_compact):
+            raise SeqRushError(-6, "only --no-sort --no-compact output is implemented "
+                                   "(compaction / Ygs sort are outside the hot path)")
+        text, _, _ = build_gfa(self.seqset, self.labels)
+        with open(args.output, "w") as fh:
+            fh.write(text)
+
+
+def run_seqrush(args: Args):
+    """src/seqrush.rs:1839-1853"""
+    sequences = load_sequences(args.sequences)
+    print(f"Loaded {len(sequences)} sequences")
+    sr = SeqRush(sequences, device=args.device)
+    sr.build_graph(args)
+    print(f"Graph written to {args.output}")
+    return sr
