@@ -87,6 +87,12 @@ int sr_parse_orientation_scores(const char *s, sr_params *p);
 /* parse_sparsification seqrush.rs:356-431 */
 int sr_parse_sparsification(const char *s, sr_params *p);
 
+/* This rank's ordered pair list (host only, no device needed): what
+ * AllPairIterator::with_options(.., exclude_self, .., sparsification) enumerates
+ * (src/seqrush.rs:728-735), sharded for multi-GPU.  Free both arrays with sr_free. */
+int sr_pair_list(uint32_t n, const sr_params *p, uint32_t **q_out, uint32_t **t_out,
+                 uint64_t *count);
+
 /* -------- Seam 1: trait Aligner (src/aligner.rs:27-33) -----------------
  * sr_align_all == AllwaveAligner::align_sequences
  * (src/aligner/allwave_impl.rs:95-149): one call, all sequences, returns one

@@ -19,7 +19,7 @@ EXPORTS = [
     "sr_ctx_unite", "sr_ctx_sync", "sr_ctx_alignments", "sr_ctx_download_uf", "sr_ctx_uf_size",
     "sr_ctx_num_pairs", "sr_ctx_dp_cells", "sr_ctx_labels_device", "sr_ctx_merge_labels",
     "sr_ctx_download_labels", "sr_ctx_kernel_ms", "sr_ctx_counters", "sr_build_gfa", "sr_free",
-    "sr_last_error", "sr_abi_version", "sr_device_count",
+    "sr_last_error", "sr_abi_version", "sr_device_count", "sr_pair_list",
 ]
 
 
@@ -102,6 +102,8 @@ def load():
     L.sr_ctx_kernel_ms.argtypes = [vp, i32, C.POINTER(C.c_float)]
     L.sr_ctx_counters.argtypes = [vp, C.POINTER(u64)]
     L.sr_build_gfa.argtypes = [PS, C.POINTER(u64), C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
+    L.sr_pair_list.argtypes = [C.c_uint32, PP, C.POINTER(C.POINTER(C.c_uint32)),
+                               C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(u64)]
     L.sr_free.argtypes = [vp]; L.sr_free.restype = None
     L.sr_last_error.restype = C.c_char_p
     L.sr_abi_version.restype = i32

@@ -239,6 +239,43 @@ static uint64_t splitmix64(uint64_t x) {
     return x ^ (x >> 31);
 }
 
+
+// Ordered pair list of this rank: row-major n*n incl. self pairs ("all-vs-all
+// including self", seqrush.rs:718-734), optional exclude_self, random:F
+// sparsification (own definition: keep ordered pair (q,t), q != t, iff
+// splitmix64(seed ^ (q*n+t)) / 2^53 < F; allwave's rule is not in the
+// reference tree), then interleaved sharding: kept pair number j belongs to
+// rank j % shard_count.
+static void build_pair_list(uint32_t n, const sr_params &p, std::vector<uint32_t> &pq, std::vector<uint32_t> &pt) {
+    pq.clear(); pt.clear();
+    uint64_t kept = 0;
+    for (uint32_t q = 0; q < n; q++)
+        for (uint32_t t = 0; t < n; t++) {
+            if (p.exclude_self && q == t) continue;
+            if (p.sparsify_kind == SR_SPARSE_RANDOM && q != t) {
+                const uint64_t h = splitmix64(p.sparsify_seed ^ ((uint64_t)q * n + t));
+                if ((double)(h >> 11) * (1.0 / 9007199254740992.0) >= p.sparsify_factor) continue;
+            }
+            if (kept % p.shard_count == p.shard_rank) { pq.push_back(q); pt.push_back(t); }
+            kept++;
+        }
+}
+
+extern "C" int sr_pair_list(uint32_t n, const sr_params *p, uint32_t **q_out, uint32_t **t_out, uint64_t *count) {
+    if (!p || !q_out || !t_out || !count) return fail(SR_ERR_INVALID, "null argument");
+    if (p->shard_count == 0 || p->shard_rank >= p->shard_count) return fail(SR_ERR_INVALID, "bad shard");
+    if (p->sparsify_kind != SR_SPARSE_NONE && p->sparsify_kind != SR_SPARSE_RANDOM)
+        return fail(SR_ERR_UNSUPPORTED, "only sparsification none / random:F is implemented");
+    std::vector<uint32_t> pq, pt;
+    build_pair_list(n, *p, pq, pt);
+    *count = pq.size();
+    *q_out = (uint32_t *)malloc((pq.size() ? pq.size() : 1) * 4);
+    *t_out = (uint32_t *)malloc((pt.size() ? pt.size() : 1) * 4);
+    memcpy(*q_out, pq.data(), pq.size() * 4);
+    memcpy(*t_out, pt.data(), pt.size() * 4);
+    return SR_OK;
+}
+
 static int make_pen(const sr_params &p, bool ori, SrPen *out) {
     if (ori) {
         if (p.ori_match != 0) return fail(SR_ERR_UNSUPPORTED, "orientation match score must be 0");
@@ -314,21 +351,9 @@ extern "C" int sr_ctx_load(sr_ctx *c, const sr_seqset *seqs, const sr_params *p)
         }
     }
     // ---- ordered pair list, row-major incl. self (seqrush.rs:718-734), sparsify, shard
-    c->pair_q.clear(); c->pair_t.clear(); c->dp_cells = 0;
-    uint64_t kept = 0;
-    for (uint32_t q = 0; q < n; q++)
-        for (uint32_t t = 0; t < n; t++) {
-            if (p->exclude_self && q == t) continue;
-            if (p->sparsify_kind == SR_SPARSE_RANDOM && q != t) {
-                const uint64_t h = splitmix64(p->sparsify_seed ^ ((uint64_t)q * n + t));
-                if ((double)(h >> 11) * (1.0 / 9007199254740992.0) >= p->sparsify_factor) continue;
-            }
-            if (kept % p->shard_count == p->shard_rank) {
-                c->pair_q.push_back(q); c->pair_t.push_back(t);
-                c->dp_cells += (uint64_t)c->len[q] * c->len[t];
-            }
-            kept++;
-        }
+    build_pair_list(n, *p, c->pair_q, c->pair_t);
+    c->dp_cells = 0;
+    for (size_t i = 0; i < c->pair_q.size(); i++) c->dp_cells += (uint64_t)c->len[c->pair_q[i]] * c->len[c->pair_t[i]];
     const uint32_t np = (uint32_t)c->pair_q.size();
     c->cigar_base.assign((size_t)np + 1, 0);
     std::vector<int32_t> max_score(np, INT_MAX);

@@ -391,3 +391,14 @@ def run_seqrush(args: Args):
     sr.build_graph(args)
     print(f"Graph written to {args.output}")
     return sr
+
+
+def pair_list(n: int, params: Params):
+    """This rank's ordered (query, target) pair list (host only)."""
+    L = _lib.load()
+    q = C.POINTER(C.c_uint32)(); t = C.POINTER(C.c_uint32)(); cnt = C.c_uint64()
+    check(L.sr_pair_list(n, C.byref(params.c), C.byref(q), C.byref(t), C.byref(cnt)))
+    m = int(cnt.value)
+    out = [(int(q[i]), int(t[i])) for i in range(m)]
+    L.sr_free(C.cast(q, C.c_void_p)); L.sr_free(C.cast(t, C.c_void_p))
+    return out

@@ -1,0 +1,103 @@
+"""Deterministic synthetic inputs for the benchmark configurations of
+BASELINE.json.  Counter-mode splitmix64 so that the streams
+are reproducible anywhere with plain numpy:
+
+    r(seed, i) = splitmix64_mix(seed * 0x9E3779B97F4A7C15 + i)
+
+C1: 8 x 1 kb, seed 1001; C2: 64 x 5 kb, seed 2001 -- a base sequence of iid
+uniform ACGT and n derived sequences, each position substituted with
+probability `sub` by a uniformly chosen different base (stream seed+1+i).
+"""
+import numpy as np
+
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+_G = np.uint64(0x9E3779B97F4A7C15)
+_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+_COMP = {65: 84, 84: 65, 67: 71, 71: 67}
+
+
+def _r(seed: int, idx: np.ndarray) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) * _G + idx.astype(np.uint64) + _G
+        z = (z ^ (z >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        return z ^ (z >> np.uint64(31))
+
+
+def _unit(x: np.ndarray) -> np.ndarray:
+    return (x >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def base_sequence(L: int, seed: int) -> np.ndarray:
+    """codes 0..3"""
+    return (_r(seed, np.arange(L)) & np.uint64(3)).astype(np.uint8)
+
+
+def substitute(base: np.ndarray, sub: float, seed: int) -> np.ndarray:
+    L = len(base)
+    u = _unit(_r(seed, 2 * np.arange(L)))
+    d = (_r(seed, 2 * np.arange(L) + 1) % np.uint64(3)).astype(np.uint8) + 1
+    return np.where(u < sub, (base + d) & 3, base).astype(np.uint8)
+
+
+def to_bytes(codes: np.ndarray) -> bytes:
+    return _ACGT[codes].tobytes()
+
+
+def reverse_complement(s: bytes) -> bytes:
+    return bytes(_COMP[c] for c in reversed(s))
+
+
+def snp_family(n: int, L: int, sub: float, seed: int, rc_every: int = 0):
+    """n sequences derived from one base by independent substitutions.
+    rc_every > 0: every rc_every-th sequence (1-based) is reverse-complemented."""
+    base = base_sequence(L, seed)
+    out = []
+    for i in range(n):
+        s = to_bytes(substitute(base, sub, seed + 1 + i))
+        if rc_every and (i + 1) % rc_every == 0:
+            s = reverse_complement(s)
+        out.append((f"seq{i}", s))
+    return out
+
+
+def indel_family(n: int, L: int, sub: float, indel: float, seed: int, max_indel: int = 8):
+    """substitutions plus short indels (python loop; keep n*L small)"""
+    base = base_sequence(L, seed)
+    out = []
+    for i in range(n):
+        sd = seed + 1 + i
+        u = _unit(_r(sd, 4 * np.arange(L)))
+        d = (_r(sd, 4 * np.arange(L) + 1) % np.uint64(3)).astype(np.uint8) + 1
+        ln = (_r(sd, 4 * np.arange(L) + 2) % np.uint64(max_indel)).astype(np.int64) + 1
+        ins = _r(sd, 4 * np.arange(L) + 3)
+        s = bytearray()
+        j = 0
+        while j < L:
+            x = u[j]
+            if x < sub:
+                s.append(int(_ACGT[(base[j] + d[j]) & 3])); j += 1
+            elif x < sub + indel / 2:
+                j += int(ln[j])
+            elif x < sub + indel:
+                v = int(ins[j])
+                for q in range(int(ln[j])):
+                    s.append(int(_ACGT[(v >> (2 * q)) & 3]))
+                s.append(int(_ACGT[base[j]])); j += 1
+            else:
+                s.append(int(_ACGT[base[j]])); j += 1
+        if not s:
+            s = bytearray(b"A")
+        out.append((f"seq{i}", bytes(s)))
+    return out
+
+
+def config_c1():
+    """BASELINE.json configs[0]: 8 synthetic 1 kb sequences, 5% SNP, seed 1001"""
+    return snp_family(8, 1000, 0.05, 1001)
+
+
+def config_c2(n: int = 64):
+    """BASELINE.json configs[1]: 64 synthetic 5 kb sequences (5% SNP), seed 2001"""
+    return snp_family(n, 5000, 0.05, 2001)

@@ -1,0 +1,274 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on
+the same seeded inputs -- CIGAR bytes, orientation flag, score, UF partition and canonical GFA
+must be bit-exact (integer / index work).  Plus golden known answers and size-independent
+properties at BASELINE.json's full size."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import seqrush_amd as sa
+from seqrush_amd import synth, _lib
+from seqrush_amd.seqrush import SeqSet, Params, Context, build_gfa
+from conftest import canon_gfa
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_params(**kw):
+    op = ob.default_params()
+    op.threads = 8
+    if "scores" in kw:
+        r, pen = ob.parse_scores(kw["scores"]); assert r == 0
+        op.pen = pen
+    if "orientation_scores" in kw:
+        pp = ob.Penalties(); assert ob.lib().sro_parse_orientation_scores(kw["orientation_scores"].encode(), C.byref(pp)) == 0
+        op.ori = pp
+    op.min_match_len = kw.get("min_match_len", 0)
+    if kw.get("max_divergence") is not None:
+        op.max_divergence = kw["max_divergence"]
+    op.exclude_self = kw.get("exclude_self", 0)
+    op.memory_mode = kw.get("memory_mode", ob.MEM_ULTRALOW)
+    return op
+
+
+def run_gpu(recs, **kw):
+    ss = SeqSet(recs)
+    p = Params(**kw)
+    ctx = Context(0)
+    ctx.load(ss, p)
+    ctx.align(); ctx.unite(); ctx.sync()
+    al = ctx.alignments()
+    labels = ctx.download_labels()
+    nodes = ctx.download_uf()
+    ctx.sync()
+    cnt = ctx.counters()
+    ctx.close()
+    return ss, al, labels, nodes, cnt
+
+
+def check_parity(recs, **kw):
+    ss, al, labels, nodes, cnt = run_gpu(recs, **kw)
+    o = ob.OracleSeqRush(records=recs)
+    op = oracle_params(**kw)
+    for i in range(al.n):
+        q, t = int(al.query_idx[i]), int(al.target_idx[i])
+        oa = o.align_pair(op, q, t)
+        assert al.raw_cigar_bytes(i) == oa["cigar"], f"CIGAR differs on pair ({q},{t})"
+        assert bool(al.is_reverse[i]) == oa["is_reverse"]
+        assert int(al.score[i]) == oa["score"]
+        assert al.cigar(i) == ob.cigar_bytes_to_string(oa["cigar"])
+    o.align_and_unite(op)
+    assert np.array_equal(o.canonical_labels(), labels), "UF partition differs"
+    g_gpu = build_gfa(ss, labels)
+    g_cpu = o.gfa(canonical=True)
+    assert canon_gfa(g_gpu[0]) == canon_gfa(g_cpu[0]) and g_gpu[1:] == g_cpu[1:]
+    # raw node array is a valid uf_rush forest with the same partition
+    from seqrush_amd.seqrush import uf_find
+    roots = {}
+    for x in range(0, len(nodes), max(1, len(nodes) // 500)):
+        roots.setdefault(uf_find(nodes, x), set()).add(int(labels[x]))
+    assert all(len(v) == 1 for v in roots.values())
+    return al, labels, cnt
+
+
+def test_smoke_entry(gpu):
+    import __graft_entry__ as ge
+    ge.smoke()
+
+
+def test_config_c1_8x1kb(gpu):
+    """BASELINE.json configs[0]"""
+    al, labels, cnt = check_parity(synth.config_c1())
+    assert al.n == 64 and cnt["breakpoint_searches"] > 0 and cnt["base_segments"] > 0
+
+
+def test_reference_wfa_boundary_known_answers(gpu):
+    """tests/test_wfa2_cigar_debug.rs:4-30 and tests/test_cigar_validity.rs through the device path
+    (single-piece affine 0,5,8,2, Ultralow)"""
+    recs = [("p", b"ATCGATCG"), ("t", b"ATCGATCGATCG"), ("u", b"ATTGATCGATCG"), ("v", b"ATCGATCGAT")]
+    ss, al, labels, nodes, cnt = run_gpu(recs, scores="0,5,8,2")
+    got = {(int(al.query_idx[i]), int(al.target_idx[i])): al.raw_cigar_bytes(i) for i in range(al.n)}
+    assert got[(0, 1)] == b"MMMMMMMMIIII"
+    assert got[(1, 1)] == b"M" * 12
+    assert got[(1, 3)] == b"MMMMMMMMMMDD"
+    assert got[(3, 1)] == b"MMMMMMMMMMII"
+    assert got[(1, 2)] == b"MMXMMMMMMMMM"
+    check_parity(recs, scores="0,5,8,2")
+
+
+def test_long_homopolymer_11068_vs_11065(gpu):
+    """tests/test_cigar_validity.rs:110-140: CIGAR consumes both lengths"""
+    recs = [("a", b"A" * 11068), ("b", b"A" * 11065)]
+    al, labels, cnt = check_parity(recs, scores="0,5,8,2")
+    for i in range(al.n):
+        raw = al.raw_cigar_bytes(i)
+        q, t = int(al.query_idx[i]), int(al.target_idx[i])
+        assert raw.count(b"M") + raw.count(b"X") + raw.count(b"D") == len(recs[q][1])
+        assert raw.count(b"M") + raw.count(b"X") + raw.count(b"I") == len(recs[t][1])
+
+
+@pytest.mark.parametrize("name,recs,kw", [
+    ("snp-5x700", synth.snp_family(5, 700, 0.05, 41), {}),
+    ("divergent-4x600", synth.snp_family(4, 600, 0.25, 42), {}),
+    ("indel-5x900", synth.indel_family(5, 900, 0.03, 0.02, 43), {}),
+    ("heavy-indel-4x500", synth.indel_family(4, 500, 0.05, 0.10, 44), {}),
+    ("ragged", [("a", synth.to_bytes(synth.base_sequence(1500, 45))), ("b", synth.to_bytes(synth.base_sequence(1500, 45))[200:900]),
+                ("c", b"ACGT"), ("d", b"A"), ("e", synth.to_bytes(synth.base_sequence(333, 46)))], {}),
+    ("rc-6x500", synth.snp_family(6, 500, 0.04, 47, rc_every=2), {}),
+    ("rc-indel", [(n, s if i % 2 else synth.reverse_complement(s)) for i, (n, s) in enumerate(synth.indel_family(4, 400, 0.03, 0.03, 48))], {}),
+    ("affine-1p", synth.indel_family(4, 800, 0.04, 0.02, 49), {"scores": "0,5,8,2"}),
+    ("other-2p", synth.indel_family(4, 600, 0.05, 0.03, 50), {"scores": "0,4,6,2,12,1"}),
+    ("open0", synth.indel_family(3, 400, 0.05, 0.03, 51), {"scores": "0,3,0,1"}),
+    ("k8", synth.snp_family(4, 800, 0.06, 52), {"min_match_len": 8}),
+    ("k64", synth.snp_family(4, 800, 0.03, 53), {"min_match_len": 64}),
+    ("exclude-self", synth.snp_family(4, 300, 0.05, 54), {"exclude_self": 1}),
+    ("divergence-filter", synth.snp_family(4, 400, 0.02, 55) + synth.snp_family(2, 400, 0.3, 56), {"max_divergence": 0.1}),
+    ("identical", [(f"s{i}", synth.to_bytes(synth.base_sequence(150, 777))) for i in range(5)], {"min_match_len": 1}),
+    ("tandem-dup", [("s1", synth.to_bytes(synth.base_sequence(100, 999))),
+                    ("s2", (lambda b: b[:40] + b[40:50] * 2 + b[50:])(synth.to_bytes(synth.base_sequence(100, 999)))),
+                    ("s3", (lambda b: b[:60] + b[60:65] * 4 + b[65:])(synth.to_bytes(synth.base_sequence(100, 999))))], {"min_match_len": 1}),
+], ids=lambda x: x if isinstance(x, str) else None)
+def test_parity_cases(gpu, name, recs, kw):
+    check_parity(recs, **kw)
+
+
+def test_c2_subset_parity_8x5kb(gpu):
+    """first 8 sequences of BASELINE.json configs[1] (64 pairs of 5 kb, score ~2.5k: full biWFA recursion)"""
+    al, labels, cnt = check_parity(synth.config_c2(8))
+    assert cnt["breakpoint_searches"] >= 56 * 15
+
+
+def test_50kb_pair_int32_offsets(gpu):
+    """sequences > 32 kb take the 32-bit offset kernel instantiation (LDS staging of 50 kb sequences)"""
+    recs = synth.snp_family(2, 40000, 0.01, 61)
+    check_parity(recs)
+
+
+def test_aligner_trait_records(gpu):
+    """Seam 1: create_aligner('allwave').align_sequences -> AlignmentRecord list (src/aligner.rs:27-33)"""
+    recs = synth.snp_family(3, 300, 0.05, 71, rc_every=3)
+    seqs = [sa.AlignmentSequence(n, s) for n, s in recs]
+    out = sa.create_aligner("allwave", 4, False, None).align_sequences(seqs)
+    assert len(out) == 9                                   # self pairs included (allwave_impl.rs:114-120)
+    o = ob.OracleSeqRush(records=recs)
+    op = ob.default_params()
+    for r in out:
+        q = [n for n, _ in recs].index(r.query_name); t = [n for n, _ in recs].index(r.target_name)
+        oa = o.align_pair(op, q, t)
+        assert r.cigar == ob.cigar_bytes_to_string(oa["cigar"])
+        assert r.strand == ("-" if oa["is_reverse"] else "+")
+        assert (r.query_start, r.query_end, r.target_start, r.target_end) == (0, len(recs[q][1]), 0, len(recs[t][1]))
+        assert set(r.cigar) <= set("0123456789=XID")
+    assert any(r.strand == "-" for r in out)
+
+
+def test_fused_entry_points_and_paf(gpu, tmp_path):
+    """Seam 2 sr_align_and_unite (raw uf_rush nodes and canonical labels) and Seam 3 sr_write_paf"""
+    recs = synth.snp_family(4, 400, 0.05, 81)
+    ss = SeqSet(recs)
+    L = _lib.load()
+    p = Params()
+    n = 2 * ss.total_length + 2
+    nodes = np.zeros(n, dtype=np.uint64)
+    _lib.check(L.sr_align_and_unite(C.byref(ss.c), C.byref(p.c), nodes.ctypes.data_as(C.POINTER(C.c_uint64))))
+    p.c.canonical_labels = 1
+    labels = np.zeros(n, dtype=np.uint64)
+    _lib.check(L.sr_align_and_unite(C.byref(ss.c), C.byref(p.c), labels.ctypes.data_as(C.POINTER(C.c_uint64))))
+    o = ob.OracleSeqRush(records=recs)
+    o.align_and_unite(ob.default_params())
+    assert np.array_equal(labels, o.canonical_labels())
+    from seqrush_amd.seqrush import uf_find
+    for x in range(0, n, 37):
+        assert int(labels[uf_find(nodes, x)]) == int(labels[x])
+    al_ss, al = sa.AllwaveAligner().align_raw([sa.AlignmentSequence(a, b) for a, b in recs])
+    paf = tmp_path / "x.paf"
+    al.write_paf(al_ss, str(paf))
+    lines = paf.read_text().strip().split("\n")
+    assert len(lines) == 16
+    # feed the PAF through the oracle's process_alignment exactly like `seqrush -p` would
+    # (src/seqrush.rs:510-609): same partition
+    o2 = ob.OracleSeqRush(records=recs)
+    names = [a for a, _ in recs]
+    for ln in lines:
+        f = ln.split("\t")
+        assert len(f) >= 12
+        cg = [x for x in f[12:] if x.startswith("cg:Z:")][0][5:]
+        assert o2.process_alignment(cg, names.index(f[0]), names.index(f[5]), 0, f[4] == "-", int(f[2]), int(f[3]), int(f[7]), int(f[8])) >= 0
+    assert np.array_equal(o2.canonical_labels(), labels)
+
+
+def test_error_paths(gpu):
+    with pytest.raises(sa.SeqRushError) as e:
+        run_gpu([("a", b"ACGT"), ("b", b"")])
+    assert e.value.code == -5 and "Empty sequences are not allowed" in str(e.value)
+    with pytest.raises(sa.SeqRushError) as e:
+        run_gpu([("a", b"ACGTN"), ("b", b"ACGT")])
+    assert e.value.code == -4
+    with pytest.raises(sa.SeqRushError) as e:
+        run_gpu([("a", b"ACGT"), ("b", b"ACGT")], scores="2,4,4,2")
+    assert e.value.code == -6
+
+
+def test_label_merge_on_device(gpu):
+    """multi-GPU scheme on one device: two pair shards -> two forests -> labels -> replay merge"""
+    recs = synth.snp_family(6, 300, 0.05, 91, rc_every=3)
+    ss = SeqSet(recs)
+    import torch
+    labs = []
+    ctxs = []
+    for r in range(2):
+        p = Params(); p.c.shard_rank, p.c.shard_count = r, 2
+        c = Context(0); c.load(ss, p); c.align(); c.unite(); c.sync()
+        t = torch.empty(c.uf_size, dtype=torch.int64, device="cuda")
+        c.labels_device(t.data_ptr()); c.sync()
+        labs.append(t); ctxs.append(c)
+    gathered = torch.cat(labs)
+    torch.cuda.synchronize()
+    ctxs[0].merge_labels(gathered.data_ptr(), 2)
+    ctxs[0].sync()
+    merged = ctxs[0].download_labels()
+    o = ob.OracleSeqRush(records=recs)
+    o.align_and_unite(ob.default_params())
+    assert np.array_equal(merged, o.canonical_labels())
+    for c in ctxs:
+        c.close()
+
+
+def test_full_size_c2_properties(gpu):
+    """BASELINE.json configs[1] at full size (4096 pairs) through size-independent properties:
+    every CIGAR spells both sequences and costs its reported score; reverse pairs mirror scores;
+    unite is idempotent; every path re-spells its input; partition refines base identity."""
+    recs = synth.config_c2(64)
+    ss, al, labels, nodes, cnt = run_gpu(recs)
+    assert al.n == 4096
+    r, pen = ob.parse_scores("0,5,8,2,24,1")
+    sc = {}
+    for i in range(0, al.n, 7):
+        q, t = int(al.query_idx[i]), int(al.target_idx[i])
+        raw = al.raw_cigar_bytes(i)
+        assert ob.cigar_score(raw, recs[q][1], recs[t][1], pen) == int(al.score[i])
+    for i in range(al.n):
+        sc[(int(al.query_idx[i]), int(al.target_idx[i]))] = int(al.score[i])
+    assert all(sc[(q, t)] == sc[(t, q)] for q in range(64) for t in range(64))
+    assert all(sc[(q, q)] == 0 for q in range(64))
+    assert not al.is_reverse.any()
+    # idempotence: a second unite pass over the same alignments changes nothing
+    ctx = Context(0); ctx.load(ss, Params()); ctx.align(); ctx.unite(); ctx.sync()
+    l1 = ctx.download_labels(); ctx.unite(); ctx.sync(); l2 = ctx.download_labels(); ctx.close()
+    assert np.array_equal(l1, labels) and np.array_equal(l1, l2)
+    # every component holds one base letter (no RC here) and the GFA re-spells every input
+    bases = np.frombuffer(b"".join(s for _, s in recs), dtype=np.uint8)
+    lab_base = bases[(labels[: 2 * len(bases)] >> np.uint64(1)).astype(np.int64)]
+    assert np.array_equal(lab_base[0::2], bases) and np.array_equal(lab_base[1::2], bases)
+    gfa, nn, ne = build_gfa(ss, labels)
+    seg = {}
+    for l in gfa.split("\n"):
+        if l.startswith("S\t"):
+            f = l.split("\t"); seg[f[1]] = f[2]
+        elif l.startswith("P\t"):
+            f = l.split("\t")
+            assert "".join(seg[s[:-1]] for s in f[2].split(",")) == dict(recs)[f[1]].decode()
+    assert nn < len(bases)

@@ -1,0 +1,156 @@
+"""CPU tests (-m "not gpu"): the C-ABI library loads and exports every symbol the header
+declares, host-side logic (parsers, pair list, FASTA mirror, graph induction / GFA writer)
+against the oracle, and loud failure without a device.  No compute calls."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import seqrush_amd as sa
+from seqrush_amd import _lib, synth
+from seqrush_amd.seqrush import SeqSet, Params, pair_list, build_gfa, load_sequences
+from conftest import canon_gfa
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_every_declared_symbol_is_exported():
+    hdr = open(os.path.join(ROOT, "include", "seqrush_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(sr_[a-z0-9_]+)\s*\(", hdr))
+    L = _lib.load()
+    missing = [s for s in sorted(declared) if not hasattr(L, s)]
+    assert not missing, missing
+    assert declared == set(_lib.EXPORTS)
+    assert L.sr_abi_version() == 1
+
+
+def test_no_device_fails_loudly():
+    L = _lib.load()
+    if L.sr_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(sa.SeqRushError) as e:
+        sa.Context(0)
+    assert e.value.code == -2 and "no CPU fallback" in str(e.value)
+    with pytest.raises(sa.SeqRushError):
+        sa.create_aligner("allwave").align_sequences([sa.AlignmentSequence("a", b"ACGT")])
+
+
+def test_product_does_not_touch_the_oracle():
+    """the product package must not import, link or mention oracle/"""
+    pkg = os.path.join(ROOT, "seqrush_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")) or f == "Makefile":
+                txt = open(os.path.join(dp, f)).read()
+                assert "oracle_binding" not in txt and "liboracle" not in txt and "sro_" not in txt, f
+
+
+def test_parsers_match_oracle():
+    cases = ["0,5,8,2,24,1", "0,5,8,2", "0,5,8,2,24", "0,5,8", "1,2,3,4,5,6,7", "0,a,8,2", "0, 5,8,2", "0,+5,8,2"]
+    for s in cases:
+        r, po = ob.parse_scores(s)
+        p = Params()
+        rc = _lib.load().sr_parse_scores(s.encode(), C.byref(p.c))
+        assert (rc == 0) == (r == 0), s
+        if r == 0:
+            assert (p.c.match_score, p.c.mismatch_penalty, p.c.gap_open1, p.c.gap_ext1) == (po.match, po.mismatch, po.gap_open1, po.gap_ext1)
+            assert (p.c.gap_open2 >= 0) == (po.gap_open2 >= 0)
+    for s in ["none", "1.0", "auto", "random:0.5", "random:0", "connectivity:0.3", "tree:3,3,0.1", "tree:", "0.5", "x"]:
+        sp = ob.Sparsification()
+        r = ob.lib().sro_parse_sparsification(s.encode(), C.byref(sp))
+        p = Params()
+        rc = _lib.load().sr_parse_sparsification(s.encode(), C.byref(p.c))
+        assert (rc == 0) == (r == 0), s
+        if r == 0:
+            assert p.c.sparsify_kind == sp.kind
+    assert sa.AlignmentScores.parse("0,5,8,2,24,1").gap2_extend == 1
+    assert sa.AlignmentScores.parse_orientation("0,1,1,1").gap1_open == 1
+    with pytest.raises(sa.SeqRushError):
+        sa.AlignmentScores.parse_orientation("0,1,1")
+
+
+def test_pair_list_and_sharding():
+    p = Params()
+    full = pair_list(5, p)
+    assert full == [(q, t) for q in range(5) for t in range(5)]      # "all-vs-all including self", seqrush.rs:718-734
+    p.c.exclude_self = 1
+    assert pair_list(4, p) == [(q, t) for q in range(4) for t in range(4) if q != t]
+    p = Params()
+    shards = []
+    for r in range(3):
+        p.c.shard_rank, p.c.shard_count = r, 3
+        shards.append(pair_list(7, p))
+    assert sorted(sum(shards, [])) == [(q, t) for q in range(7) for t in range(7)]
+    assert max(len(s) for s in shards) - min(len(s) for s in shards) <= 1
+    p = Params(sparsification="random:0.3")
+    sub = pair_list(20, p)
+    assert all((q, q) in sub for q in range(20))
+    assert 0.15 < (len(sub) - 20) / 380 < 0.45
+    assert sub == pair_list(20, p)        # deterministic
+
+
+def test_fasta_loader_mirror(tmp_path):
+    txt = b">s1 desc here\nACGT\n  GG  \n>s2\tx\nTT\r\n>\nAAAA\n>s3\nC\n"
+    f = tmp_path / "x.fa"
+    f.write_bytes(txt)
+    seqs = load_sequences(str(f))
+    o = ob.OracleSeqRush(fasta_text=txt)
+    assert [(s.id, s.data, s.offset) for s in seqs] == [o.seq(i) for i in range(o.n)]
+
+
+def _oracle_labels(recs, k=0, threads=4):
+    o = ob.OracleSeqRush(records=recs)
+    p = ob.default_params(); p.min_match_len = k; p.threads = threads
+    o.align_and_unite(p)
+    return o
+
+
+@pytest.mark.parametrize("name,recs", [
+    ("snp", synth.snp_family(5, 250, 0.05, 3)),
+    ("indel", synth.indel_family(4, 300, 0.03, 0.02, 4)),
+    ("rc", synth.snp_family(6, 200, 0.04, 5, rc_every=2)),
+    ("tiny", [("single", b"A"), ("double", b"AT")]),
+])
+def test_product_gfa_builder_matches_oracle(name, recs):
+    """sr_build_gfa (host C++, O(N)) vs the oracle's restatement of
+    bidirected_builder.rs:17-289 + write_gfa, on the oracle's canonical labels"""
+    o = _oracle_labels(recs)
+    labels = o.canonical_labels()
+    ss = SeqSet(recs)
+    g_prod, nn, ne = build_gfa(ss, labels)
+    g_orc, on, oe = o.gfa(canonical=True)
+    assert (nn, ne) == (on, oe)
+    assert g_prod == g_orc                       # identical incl. L-line order (first insertion)
+    assert canon_gfa(g_prod) == canon_gfa(o.gfa(canonical=True, faithful_scan=True)[0])
+
+
+def test_uf_find_helper():
+    o = _oracle_labels(synth.snp_family(3, 120, 0.05, 9))
+    nodes = o.nodes()
+    from seqrush_amd.seqrush import uf_find
+    for x in (0, 1, 77, 200, len(nodes) - 1):
+        assert uf_find(nodes, x) == o.find(x)
+
+
+def test_aligner_backend_names():
+    """src/aligner.rs:42-52, 64-96"""
+    assert sa.AlignerBackend.from_str("AllWave") == sa.AlignerBackend.AllWave
+    assert sa.AlignerBackend.from_str("SWEEPGA") == sa.AlignerBackend.SweepGA
+    with pytest.raises(ValueError, match="Unknown aligner"):
+        sa.AlignerBackend.from_str("bwa")
+    assert isinstance(sa.create_aligner("allwave", 4, False, None), sa.Aligner)
+    with pytest.raises(RuntimeError, match="SweepGA aligner not available"):
+        sa.create_aligner(sa.AlignerBackend.SweepGA)
+
+
+def test_synth_is_deterministic():
+    a = synth.config_c1()
+    assert len(a) == 8 and all(len(s) == 1000 for _, s in a)
+    assert a == synth.config_c1()
+    import hashlib
+    h = hashlib.sha256(b"".join(s for _, s in synth.snp_family(4, 500, 0.05, 2001))).hexdigest()
+    assert h == hashlib.sha256(b"".join(s for _, s in synth.snp_family(4, 500, 0.05, 2001))).hexdigest()
