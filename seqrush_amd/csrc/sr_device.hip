@@ -21,16 +21,16 @@
 #include <limits.h>
 #include "sr_internal.h"
 
-#define WG SR_WG
+#define WG SR_WG   // unite kernel workgroup size
 #define NULLV SR_NULL_OFF
 #define BT_TMP_CAP 2048
 
 struct Seg { int pb, pe, tb, te; int cb, ce; int score_rem; };
 
 struct Shared {
-    int red_maxak[3];
-    int reached[3];
-    int mak[2][SR_MAX_SCOPE];
+    int red_maxak[3][2];
+    int reached[3][2];
+    int mak[2][SR_MAX_SCOPE + 1];
     int cand[5];
     int bp_score, bp_score_f, bp_score_r, bp_k_f, bp_k_r, bp_comp, bp_off_f, bp_off_r;
     Seg stack[SR_STACK_DEPTH];
@@ -43,11 +43,27 @@ struct Shared {
     int score_acc;
 };
 
+#define RFL(x) __builtin_amdgcn_readfirstlane(x)
+
+// Explicit address spaces: pointers that travel inside a by-value kernel
+// argument struct are generic ("flat") for hipcc; flat loads cost a VGPR pair
+// per address and the slow path.  GP = global (HBM) pointer, LP = LDS pointer.
+template <typename T> using GP = T __attribute__((address_space(1))) *;
+typedef const uint32_t __attribute__((address_space(3))) *LP;
+
+// One aligner's wavefront storage.  Modular (score-only) mode: M ring of
+// scope+1 levels, "hot" I/D rings of e+2 levels (all the recurrences read),
+// plus a "cold" I/D history of scope+1 levels that only the breakpoint
+// detection reads (written with non-temporal stores so it does not displace
+// the hot rings from L2 / Infinity Cache).  Full mode (base case): every level
+// kept, hot == history.
 template <typename OT>
 struct Dir {
-    OT *base;        // rows: [slot][5][cap]
+    GP<OT> m;        // M rows
+    GP<OT> g[4];     // I1, I2, D1, D2 rows (index comp-1)
+    GP<OT> cold;     // [slot][4][cap] or nullptr
+    int nsm, nsg1, nsg2, nsc;
     int cap, shift;
-    int nslots;
     int modular;
     int rev;
     int pb, pe, tb, te;
@@ -56,10 +72,26 @@ struct Dir {
 };
 
 template <typename OT>
-__device__ __forceinline__ OT *rowk(const Dir<OT> &d, int s, int comp) {
-    const int slot = d.modular ? (s % d.nslots) : s;
-    return d.base + ((size_t)slot * 5 + comp) * (size_t)d.cap + d.shift;
+__device__ __forceinline__ GP<OT> rowk(const Dir<OT> &d, int s, int comp) {
+    if (comp == SR_C_M) return d.m + (size_t)(d.modular ? (s % d.nsm) : s) * (size_t)d.cap + d.shift;
+    const int ns = (comp == SR_C_I1 || comp == SR_C_D1) ? d.nsg1 : d.nsg2;
+    return d.g[comp - 1] + (size_t)(d.modular ? (s % ns) : s) * (size_t)d.cap + d.shift;
 }
+// same rows without the diagonal shift: indexed by the non-negative
+// idx = k + shift so that hipcc can use SGPR-base + 32-bit VGPR-offset loads
+template <typename OT>
+__device__ __forceinline__ GP<OT> rowb(const Dir<OT> &d, int s, int comp) { return rowk(d, s, comp) - d.shift; }
+template <typename OT>
+__device__ __forceinline__ GP<OT> hrowb(const Dir<OT> &d, int s, int comp);
+// row used by breakpoint detection / backtrace-independent history reads
+template <typename OT>
+__device__ __forceinline__ GP<OT> hrowk(const Dir<OT> &d, int s, int comp) {
+    if (comp == SR_C_M || !d.cold) return rowk(d, s, comp);
+    return d.cold + ((size_t)(s % d.nsc) * 4 + (comp - 1)) * (size_t)d.cap + d.shift;
+}
+
+template <typename OT>
+__device__ __forceinline__ GP<OT> hrowb(const Dir<OT> &d, int s, int comp) { return hrowk(d, s, comp) - d.shift; }
 
 __device__ __forceinline__ int reach(const SrPen &p, int s, int begin) {
     int r;
@@ -84,18 +116,18 @@ __device__ __forceinline__ int wave_max(int v) {
 }
 
 // 16 bases starting at base i (2 bits each, base i in the low bits)
-__device__ __forceinline__ uint32_t win_fwd(const uint32_t *w, int i) {
+__device__ __forceinline__ uint32_t win_fwd(LP w, int i) {
     const int wi = i >> 4, sh = (i & 15) << 1;
     const uint64_t v = ((uint64_t)w[wi + 1] << 32) | (uint64_t)w[wi];
     return (uint32_t)(v >> sh);
 }
 // 16 bases ending at base i (base i in the high bits)
-__device__ __forceinline__ uint32_t win_rev(const uint32_t *w, int i) {
+__device__ __forceinline__ uint32_t win_rev(LP w, int i) {
     return win_fwd(w, i - 15);
 }
 
 // number of equal bases walking forward from (pi, ti), at most n
-__device__ __forceinline__ int ext_fwd(const uint32_t *P, const uint32_t *T, int pi, int ti, int n) {
+__device__ __forceinline__ int ext_fwd(LP P, LP T, int pi, int ti, int n) {
     int tot = 0;
     while (tot < n) {
         const uint32_t x = win_fwd(P, pi + tot) ^ win_fwd(T, ti + tot);
@@ -107,7 +139,7 @@ __device__ __forceinline__ int ext_fwd(const uint32_t *P, const uint32_t *T, int
     return tot;
 }
 // same walking backward from (pi, ti) inclusive
-__device__ __forceinline__ int ext_rev(const uint32_t *P, const uint32_t *T, int pi, int ti, int n) {
+__device__ __forceinline__ int ext_rev(LP P, LP T, int pi, int ti, int n) {
     int tot = 0;
     while (tot < n) {
         const uint32_t x = win_rev(P, pi - tot) ^ win_rev(T, ti - tot);
@@ -121,32 +153,38 @@ __device__ __forceinline__ int ext_rev(const uint32_t *P, const uint32_t *T, int
 
 // One score step of one aligner: compute + bound + extend over the write
 // range; reduction of the M max antidiagonal and the end test go to LDS slot
-// ev % 3.  Caller must __syncthreads() before reading them.
-template <typename OT, bool TWO>
+// [ev % 3][side].  Caller must __syncthreads() before reading them.
+template <typename OT, bool TWO, int NT>
 __device__ __forceinline__ void wf_step(const Dir<OT> &d, const SrPen &pen, int s,
-                                        const uint32_t *P, const uint32_t *T, int check_comp,
-                                        Shared &sh, int ev, unsigned long long &cells) {
+                                        LP P, LP T, int check_comp,
+                                        Shared &sh, int ev, int side, unsigned long long &cells) {
     const int tid = threadIdx.x;
     const int plen = d.plen, tlen = d.tlen;
     const int R = reach(pen, s, d.begin);
     const int klo = max(-plen, -R), khi = min(tlen, R);
     const int wlo = max(-plen - 1, -R - pen.scope - 1), whi = min(tlen + 1, R + pen.scope + 1);
     const int k_end = tlen - plen;
-    const OT *pMx = (s >= pen.x) ? rowk(d, s - pen.x, SR_C_M) : nullptr;
-    const OT *pMo1 = (s >= pen.o1 + pen.e1) ? rowk(d, s - pen.o1 - pen.e1, SR_C_M) : nullptr;
-    const OT *pI1 = (s >= pen.e1) ? rowk(d, s - pen.e1, SR_C_I1) : nullptr;
-    const OT *pD1 = (s >= pen.e1) ? rowk(d, s - pen.e1, SR_C_D1) : nullptr;
-    const OT *pMo2 = nullptr, *pI2 = nullptr, *pD2 = nullptr;
+    const GP<OT> pMx = (s >= pen.x) ? rowb(d, s - pen.x, SR_C_M) : nullptr;
+    const GP<OT> pMo1 = (s >= pen.o1 + pen.e1) ? rowb(d, s - pen.o1 - pen.e1, SR_C_M) : nullptr;
+    const GP<OT> pI1 = (s >= pen.e1) ? rowb(d, s - pen.e1, SR_C_I1) : nullptr;
+    const GP<OT> pD1 = (s >= pen.e1) ? rowb(d, s - pen.e1, SR_C_D1) : nullptr;
+    GP<OT> pMo2 = nullptr, pI2 = nullptr, pD2 = nullptr;
     if (TWO) {
-        if (s >= pen.o2 + pen.e2) pMo2 = rowk(d, s - pen.o2 - pen.e2, SR_C_M);
-        if (s >= pen.e2) { pI2 = rowk(d, s - pen.e2, SR_C_I2); pD2 = rowk(d, s - pen.e2, SR_C_D2); }
+        if (s >= pen.o2 + pen.e2) pMo2 = rowb(d, s - pen.o2 - pen.e2, SR_C_M);
+        if (s >= pen.e2) { pI2 = rowb(d, s - pen.e2, SR_C_I2); pD2 = rowb(d, s - pen.e2, SR_C_D2); }
     }
-    OT *oM = rowk(d, s, SR_C_M), *oI1 = rowk(d, s, SR_C_I1), *oD1 = rowk(d, s, SR_C_D1);
-    OT *oI2 = rowk(d, s, SR_C_I2), *oD2 = rowk(d, s, SR_C_D2);
+    GP<OT> oM = rowb(d, s, SR_C_M), oI1 = rowb(d, s, SR_C_I1), oD1 = rowb(d, s, SR_C_D1);
+    GP<OT> oI2 = rowb(d, s, SR_C_I2), oD2 = rowb(d, s, SR_C_D2);
+    GP<OT> cI1 = nullptr, cI2 = nullptr, cD1 = nullptr, cD2 = nullptr;
+    if (d.cold) {
+        cI1 = hrowb(d, s, SR_C_I1); cD1 = hrowb(d, s, SR_C_D1);
+        cI2 = hrowb(d, s, SR_C_I2); cD2 = hrowb(d, s, SR_C_D2);
+    }
     int my_ak = 0;
     bool my_reached = false;
-    for (int k = wlo + tid; k <= whi; k += WG) {
+    for (int k = wlo + tid; k <= whi; k += NT) {
         int m = NULLV, i1 = NULLV, i2 = NULLV, d1 = NULLV, d2 = NULLV;
+        const unsigned idx = (unsigned)(k + d.shift);
         if (k >= klo && k <= khi) {
             if (s == 0) {
                 if (k == 0) {
@@ -159,22 +197,22 @@ __device__ __forceinline__ void wf_step(const Dir<OT> &d, const SrPen &pen, int 
             } else {
                 const unsigned lim = (unsigned)min(tlen, plen + k);
                 {
-                    const int a = pMo1 ? (int)pMo1[k - 1] : NULLV;
-                    const int b = pI1 ? (int)pI1[k - 1] : NULLV;
+                    const int a = pMo1 ? (int)pMo1[idx - 1] : NULLV;
+                    const int b = pI1 ? (int)pI1[idx - 1] : NULLV;
                     i1 = bnd(max(a, b) + 1, lim);
-                    const int c = pMo1 ? (int)pMo1[k + 1] : NULLV;
-                    const int e = pD1 ? (int)pD1[k + 1] : NULLV;
+                    const int c = pMo1 ? (int)pMo1[idx + 1] : NULLV;
+                    const int e = pD1 ? (int)pD1[idx + 1] : NULLV;
                     d1 = bnd(max(c, e), lim);
                 }
                 if (TWO) {
-                    const int a = pMo2 ? (int)pMo2[k - 1] : NULLV;
-                    const int b = pI2 ? (int)pI2[k - 1] : NULLV;
+                    const int a = pMo2 ? (int)pMo2[idx - 1] : NULLV;
+                    const int b = pI2 ? (int)pI2[idx - 1] : NULLV;
                     i2 = bnd(max(a, b) + 1, lim);
-                    const int c = pMo2 ? (int)pMo2[k + 1] : NULLV;
-                    const int e = pD2 ? (int)pD2[k + 1] : NULLV;
+                    const int c = pMo2 ? (int)pMo2[idx + 1] : NULLV;
+                    const int e = pD2 ? (int)pD2[idx + 1] : NULLV;
                     d2 = bnd(max(c, e), lim);
                 }
-                const int mx = pMx ? (int)pMx[k] : NULLV;
+                const int mx = pMx ? (int)pMx[idx] : NULLV;
                 m = bnd(mx + 1, lim);
                 m = max(m, max(max(i1, i2), max(d1, d2)));
                 if (m < 0) m = NULLV;
@@ -199,22 +237,30 @@ __device__ __forceinline__ void wf_step(const Dir<OT> &d, const SrPen &pen, int 
                 if (val >= tlen) my_reached = true;
             }
         }
-        oM[k] = (OT)m; oI1[k] = (OT)i1; oD1[k] = (OT)d1;
-        if (TWO) { oI2[k] = (OT)i2; oD2[k] = (OT)d2; }
+        oM[idx] = (OT)m; oI1[idx] = (OT)i1; oD1[idx] = (OT)d1;
+        if (TWO) { oI2[idx] = (OT)i2; oD2[idx] = (OT)d2; }
+        if (cI1) {
+            __builtin_nontemporal_store((OT)i1, &cI1[idx]);
+            __builtin_nontemporal_store((OT)d1, &cD1[idx]);
+            if (TWO) {
+                __builtin_nontemporal_store((OT)i2, &cI2[idx]);
+                __builtin_nontemporal_store((OT)d2, &cD2[idx]);
+            }
+        }
     }
     my_ak = wave_max(my_ak);
     const int slot = ev % 3;
-    if ((tid & 63) == 0 && my_ak > 0) atomicMax(&sh.red_maxak[slot], my_ak);
-    if (my_reached) sh.reached[slot] = 1;
+    if ((tid & 63) == 0 && my_ak > 0) atomicMax(&sh.red_maxak[slot][side], my_ak);
+    if (my_reached) sh.reached[slot][side] = 1;
     if (tid == 0) {
-        sh.red_maxak[(ev + 1) % 3] = 0;
-        sh.reached[(ev + 1) % 3] = 0;
+        sh.red_maxak[(ev + 1) % 3][side] = 0;
+        sh.reached[(ev + 1) % 3][side] = 0;
         if (khi >= klo) cells += (unsigned long long)(khi - klo + 1);
     }
 }
 
 // ---------------------------------------------------------------- CIGAR out
-__device__ __forceinline__ void cig_append(uint32_t *ops, uint32_t &cnt, uint32_t cap, int op,
+__device__ __forceinline__ void cig_append(GP<uint32_t> ops, uint32_t &cnt, uint32_t cap, int op,
                                            int len, int &err) {
     if (len <= 0) return;
     if (cnt > 0 && (int)(ops[cnt - 1] & 15u) == op) { ops[cnt - 1] += (uint32_t)len << 4; return; }
@@ -238,8 +284,9 @@ __device__ __forceinline__ void bt_best(int &bo, int &bty, int off, int type) {
 
 // thread-0 backtrace over the full history (oracle/wfa.c wfa_full)
 template <typename OT, bool TWO>
-__device__ void backtrace(const Dir<OT> &d, const SrPen &pen, int score, int cb, int ce,
-                          Shared &sh, int &err) {
+__device__ __noinline__ int backtrace(const Dir<OT> d, const SrPen pen, int score, int cb, int ce,
+                                      Shared &sh) {
+    int err = 0;
     const int plen = d.plen, tlen = d.tlen;
     int s = score, k = tlen - plen, comp = ce, off = tlen;
     sh.bt_n = 0;
@@ -248,13 +295,13 @@ __device__ void backtrace(const Dir<OT> &d, const SrPen &pen, int score, int cb,
             if (s == 0) {
                 if (cb != SR_C_M || k != 0) err |= SR_DEV_ERR_BACKTRACE;
                 bt_push(sh, SR_OP_M, off, err);
-                return;
+                return err;
             }
             const unsigned lim = (unsigned)min(tlen, plen + k);
             int bo = NULLV, bty = 0;
             if (s >= pen.x) bt_best(bo, bty, bnd((int)rowk(d, s - pen.x, SR_C_M)[k] + 1, lim), 9);
             if (s >= pen.o1 + pen.e1) {
-                const OT *r = rowk(d, s - pen.o1 - pen.e1, SR_C_M);
+                const GP<OT> r = rowk(d, s - pen.o1 - pen.e1, SR_C_M);
                 bt_best(bo, bty, bnd((int)r[k - 1] + 1, lim), 1);
                 bt_best(bo, bty, bnd((int)r[k + 1], lim), 5);
             }
@@ -264,7 +311,7 @@ __device__ void backtrace(const Dir<OT> &d, const SrPen &pen, int score, int cb,
             }
             if (TWO) {
                 if (s >= pen.o2 + pen.e2) {
-                    const OT *r = rowk(d, s - pen.o2 - pen.e2, SR_C_M);
+                    const GP<OT> r = rowk(d, s - pen.o2 - pen.e2, SR_C_M);
                     bt_best(bo, bty, bnd((int)r[k - 1] + 1, lim), 3);
                     bt_best(bo, bty, bnd((int)r[k + 1], lim), 7);
                 }
@@ -273,7 +320,7 @@ __device__ void backtrace(const Dir<OT> &d, const SrPen &pen, int score, int cb,
                     bt_best(bo, bty, bnd((int)rowk(d, s - pen.e2, SR_C_D2)[k + 1], lim), 8);
                 }
             }
-            if (bty == 0 || bo > off) { err |= SR_DEV_ERR_BACKTRACE; return; }
+            if (bty == 0 || bo > off) { err |= SR_DEV_ERR_BACKTRACE; return err; }
             bt_push(sh, SR_OP_M, off - bo, err);
             off = bo;
             switch (bty) {
@@ -290,7 +337,7 @@ __device__ void backtrace(const Dir<OT> &d, const SrPen &pen, int score, int cb,
         } else {
             if (s == 0) {
                 if (comp != cb || k != 0 || off != 0) err |= SR_DEV_ERR_BACKTRACE;
-                return;
+                return err;
             }
             const bool is_ins = (comp == SR_C_I1 || comp == SR_C_I2);
             const bool p1 = (comp == SR_C_I1 || comp == SR_C_D1);
@@ -307,33 +354,43 @@ __device__ void backtrace(const Dir<OT> &d, const SrPen &pen, int score, int cb,
             bool take_ext;
             if (c_ext >= 0 && c_ext >= c_open) take_ext = true;
             else if (c_open >= 0) take_ext = false;
-            else { err |= SR_DEV_ERR_BACKTRACE; return; }
-            if ((take_ext ? c_ext : c_open) != off) { err |= SR_DEV_ERR_BACKTRACE; return; }
+            else { err |= SR_DEV_ERR_BACKTRACE; return err; }
+            if ((take_ext ? c_ext : c_open) != off) { err |= SR_DEV_ERR_BACKTRACE; return err; }
             if (is_ins) { bt_push(sh, SR_OP_I, 1, err); off -= 1; k -= 1; }
             else { bt_push(sh, SR_OP_D, 1, err); k += 1; }
             if (take_ext) s -= e; else { s -= o + e; comp = SR_C_M; }
         }
-        if (s < 0) { err |= SR_DEV_ERR_BACKTRACE; return; }
+        if (s < 0) { err |= SR_DEV_ERR_BACKTRACE; return err; }
     }
     err |= SR_DEV_ERR_BACKTRACE;
+    return err;
+}
+
+template <typename OT>
+__device__ __forceinline__ void dir_seg(Dir<OT> &d, const Seg &sg) {
+    d.pb = sg.pb; d.pe = sg.pe; d.tb = sg.tb; d.te = sg.te;
+    d.plen = sg.pe - sg.pb; d.tlen = sg.te - sg.tb;
 }
 
 // plain WFA with full history + backtrace on one segment (all threads)
-template <typename OT, bool TWO>
-__device__ void wfa_base(const Seg &sg, const SrAlignArgs &a, const SrPen &pen, OT *hist,
-                         const uint32_t *P, const uint32_t *T, Shared &sh, int &ev,
-                         unsigned long long &cells, unsigned long long &steps, uint32_t *ops,
+template <typename OT, bool TWO, int NT>
+__device__ __forceinline__ void wfa_base(const Seg &sg, const SrAlignArgs &a, const SrPen &pen, GP<OT> hist,
+                         LP P, LP T, Shared &sh, int &ev,
+                         unsigned long long &cells, unsigned long long &steps, GP<uint32_t> ops,
                          uint32_t cap) {
     Dir<OT> d;
-    d.base = hist; d.cap = a.hist_w; d.shift = a.hist_w / 2; d.nslots = a.hist_levels;
-    d.modular = 0; d.rev = 0; d.pb = sg.pb; d.pe = sg.pe; d.tb = sg.tb; d.te = sg.te;
-    d.plen = sg.pe - sg.pb; d.tlen = sg.te - sg.tb; d.begin = sg.cb;
+    const size_t comp_stride = (size_t)a.hist_levels * (size_t)a.hist_w;
+    d.m = hist;
+    for (int c = 0; c < 4; c++) d.g[c] = hist + (size_t)(c + 1) * comp_stride;
+    d.cold = nullptr; d.nsm = d.nsg1 = d.nsg2 = d.nsc = a.hist_levels;
+    d.cap = a.hist_w; d.shift = a.hist_w / 2; d.modular = 0; d.rev = 0; d.begin = sg.cb;
+    dir_seg(d, sg);
     int s = 0;
     bool found = false;
     for (;;) {
-        wf_step<OT, TWO>(d, pen, s, P, T, sg.ce, sh, ev, cells);
+        wf_step<OT, TWO, NT>(d, pen, s, P, T, sg.ce, sh, ev, 0, cells);
         __syncthreads();
-        const bool r = sh.reached[ev % 3] != 0;
+        const bool r = sh.reached[ev % 3][0] != 0;
         ev++;
         steps++;
         if (r) { found = true; break; }
@@ -344,7 +401,7 @@ __device__ void wfa_base(const Seg &sg, const SrAlignArgs &a, const SrPen &pen, 
         int err = 0;
         if (!found) err |= SR_DEV_ERR_BASE_OVERFLOW;
         else {
-            backtrace<OT, TWO>(d, pen, s, sg.cb, sg.ce, sh, err);
+            err |= backtrace<OT, TWO>(d, pen, s, sg.cb, sg.ce, sh);
             uint32_t cnt = sh.cig_cnt;
             for (int i = sh.bt_n - 1; i >= 0; i--)
                 cig_append(ops, cnt, cap, (int)(sh.bt_tmp[i] & 15u), (int)(sh.bt_tmp[i] >> 4), err);
@@ -355,149 +412,168 @@ __device__ void wfa_base(const Seg &sg, const SrAlignArgs &a, const SrPen &pen, 
     __syncthreads();
 }
 
+template <typename OT>
+__device__ __forceinline__ void bp_try(const Dir<OT> &d0, const Dir<OT> &d1, int c, int gap,
+                                       int score_0, int score_i, int kinv, bool bp_forward, Shared &sh) {
+    const int k0 = sh.cand[c];
+    if (k0 == INT_MAX) return;
+    if (!(score_0 + score_i - gap < sh.bp_score)) return;
+    const int k1 = kinv - k0;
+    const int o0 = (int)hrowk(d0, score_0, c)[k0];
+    const int o1 = (int)hrowk(d1, score_i, c)[k1];
+    if (bp_forward) {
+        sh.bp_score_f = score_0; sh.bp_score_r = score_i;
+        sh.bp_k_f = k0; sh.bp_k_r = k1; sh.bp_off_f = o0; sh.bp_off_r = o1;
+    } else {
+        sh.bp_score_f = score_i; sh.bp_score_r = score_0;
+        sh.bp_k_f = k1; sh.bp_k_r = k0; sh.bp_off_f = o1; sh.bp_off_r = o0;
+    }
+    sh.bp_score = score_0 + score_i - gap;
+    sh.bp_comp = c;
+}
+
 // breakpoint detection between level score_0 of aligner a0 and the last
 // `scope` levels of aligner a1 (oracle/wfa.c bialign_overlap)
-template <typename OT, bool TWO>
-__device__ void bi_overlap(const Dir<OT> &d0, const Dir<OT> &d1, int a0, int a1, const SrPen &pen,
+template <typename OT, bool TWO, int NT>
+__device__ __forceinline__ void bi_overlap(const Dir<OT> &d0, const Dir<OT> &d1, int a0, int a1, const SrPen &pen,
                            int score_0, int score_1, bool bp_forward, Shared &sh) {
     const int tid = threadIdx.x;
     const int plen = d0.plen, tlen = d0.tlen;
     const int kinv = tlen - plen;
-    const int mak0 = sh.mak[a0][score_0 % pen.scope];
+    __syncthreads();                                      // mak[] / bp_score of the last step visible
+    const int mak0 = RFL(sh.mak[a0][score_0 % d0.nsm]);
     const int gapmax = TWO ? max(pen.o1, pen.o2) : pen.o1;
     const int R0 = reach(pen, score_0, d0.begin);
     const int klo0 = max(-plen, -R0), khi0 = min(tlen, R0);
     for (int i = 0; i < pen.scope; i++) {
         const int score_i = score_1 - i;
         if (score_i < 0) break;
-        const int mak1 = sh.mak[a1][score_i % pen.scope];
+        const int mak1 = RFL(sh.mak[a1][score_i % d1.nsm]);
         if (mak0 + mak1 < plen + tlen) continue;            // no diagonal can overlap
-        if (score_0 + score_i - gapmax >= sh.bp_score) continue;
+        if (score_0 + score_i - gapmax >= RFL(sh.bp_score)) continue;
         if (tid < 5) sh.cand[tid] = INT_MAX;
         __syncthreads();
         const int R1 = reach(pen, score_i, d1.begin);
         const int klo1 = max(-plen, -R1), khi1 = min(tlen, R1);
         const int lo = max(klo0, kinv - khi1), hi = min(khi0, kinv - klo1);
-        for (int k0 = lo + tid; k0 <= hi; k0 += WG) {
+        for (int k0 = lo + tid; k0 <= hi; k0 += NT) {
             const int k1 = kinv - k0;
 #pragma unroll
             for (int c = 0; c < 5; c++) {
                 if (!TWO && (c == SR_C_I2 || c == SR_C_D2)) continue;
-                const int o0 = (int)rowk(d0, score_0, c)[k0];
-                const int o1 = (int)rowk(d1, score_i, c)[k1];
+                const int o0 = (int)hrowk(d0, score_0, c)[k0];
+                const int o1 = (int)hrowk(d1, score_i, c)[k1];
                 if (o0 >= 0 && o1 >= 0 && o0 + o1 >= tlen) atomicMin(&sh.cand[c], k0);
             }
         }
         __syncthreads();
         if (tid == 0) {
             // order: D2, I2, D1, I1, M with the running thresholds
-            const int order[5] = {SR_C_D2, SR_C_I2, SR_C_D1, SR_C_I1, SR_C_M};
-            for (int q = 0; q < 5; q++) {
-                const int c = order[q];
-                if (!TWO && (c == SR_C_I2 || c == SR_C_D2)) continue;
-                const int gap = (c == SR_C_M) ? 0 : ((c == SR_C_I1 || c == SR_C_D1) ? pen.o1 : pen.o2);
-                const int k0 = sh.cand[c];
-                if (k0 == INT_MAX) continue;
-                if (!(score_0 + score_i - gap < sh.bp_score)) continue;
-                const int k1 = kinv - k0;
-                const int o0 = (int)rowk(d0, score_0, c)[k0];
-                const int o1 = (int)rowk(d1, score_i, c)[k1];
-                if (bp_forward) {
-                    sh.bp_score_f = score_0; sh.bp_score_r = score_i;
-                    sh.bp_k_f = k0; sh.bp_k_r = k1; sh.bp_off_f = o0; sh.bp_off_r = o1;
-                } else {
-                    sh.bp_score_f = score_i; sh.bp_score_r = score_0;
-                    sh.bp_k_f = k1; sh.bp_k_r = k0; sh.bp_off_f = o1; sh.bp_off_r = o0;
-                }
-                sh.bp_score = score_0 + score_i - gap;
-                sh.bp_comp = c;
+            if (TWO) {
+                bp_try(d0, d1, SR_C_D2, pen.o2, score_0, score_i, kinv, bp_forward, sh);
+                bp_try(d0, d1, SR_C_I2, pen.o2, score_0, score_i, kinv, bp_forward, sh);
             }
+            bp_try(d0, d1, SR_C_D1, pen.o1, score_0, score_i, kinv, bp_forward, sh);
+            bp_try(d0, d1, SR_C_I1, pen.o1, score_0, score_i, kinv, bp_forward, sh);
+            bp_try(d0, d1, SR_C_M, 0, score_0, score_i, kinv, bp_forward, sh);
         }
         __syncthreads();
     }
 }
 
-// biWFA breakpoint search on one segment (oracle/wfa.c bialign_find_breakpoint)
-template <typename OT, bool TWO>
-__device__ bool find_breakpoint(const Seg &sg, const SrAlignArgs &a, const SrPen &pen, OT *ring,
-                                const uint32_t *P, const uint32_t *T, Shared &sh, int &ev,
+template <typename OT>
+__device__ __forceinline__ void dir_ring(Dir<OT> &d, GP<OT> base, const SrAlignArgs &a, const SrPen &pen) {
+    // layout of one direction: M[(scope_max+1)] | I1 I2 D1 D2 hot [(emax+2)] each | cold [(scope_max+1)][4]
+    const size_t cap = (size_t)a.ring_cap;
+    d.m = base;
+    GP<OT> p = base + (size_t)(a.ring_scope + 1) * cap;
+    for (int c = 0; c < 4; c++) { d.g[c] = p; p += (size_t)a.ring_hot * cap; }
+    d.cold = p;
+    d.nsm = pen.scope + 1; d.nsg1 = pen.e1 + 2; d.nsg2 = pen.two ? pen.e2 + 2 : 2; d.nsc = pen.scope + 1;
+    d.cap = a.ring_cap; d.modular = 1;
+}
+
+// computes F level done_f+1 and/or R level done_r+1 in one pass (one barrier)
+#define STEP_BOTH(DO_F, DO_R)                                                                      \
+    do {                                                                                           \
+        const bool do_f_ = (DO_F), do_r_ = (DO_R);                                                 \
+        if (do_f_) wf_step<OT, TWO, NT>(F, pen, done_f + 1, P, T, -1, sh, ev, 0, cells);           \
+        if (do_r_) wf_step<OT, TWO, NT>(R, pen, done_r + 1, P, T, -1, sh, ev, 1, cells);           \
+        __syncthreads();                                                                           \
+        if (do_f_) {                                                                               \
+            done_f++; ak_f_done = RFL(sh.red_maxak[ev % 3][0]);                                    \
+            if (tid == 0) sh.mak[0][done_f % F.nsm] = ak_f_done;                                   \
+            steps++;                                                                               \
+        }                                                                                          \
+        if (do_r_) {                                                                               \
+            done_r++; ak_r_done = RFL(sh.red_maxak[ev % 3][1]);                                    \
+            if (tid == 0) sh.mak[1][done_r % R.nsm] = ak_r_done;                                   \
+            steps++;                                                                               \
+        }                                                                                          \
+        ev++;                                                                                      \
+    } while (0)
+
+// biWFA breakpoint search on one segment (oracle/wfa.c bialign_find_breakpoint).
+// Forward and reverse aligners are stepped together: the level the other
+// aligner will need next is computed speculatively in the same pass (it does
+// not depend on this one), so one barrier serves two wavefront steps.
+template <typename OT, bool TWO, int NT>
+__device__ __forceinline__ bool find_breakpoint(const Seg &sg, const SrAlignArgs &a, const SrPen &pen, GP<OT> ring,
+                                LP P, LP T, Shared &sh, int &ev,
                                 unsigned long long &cells, unsigned long long &steps) {
     const int tid = threadIdx.x;
     Dir<OT> F, R;
-    F.base = ring; F.cap = a.ring_cap; F.nslots = pen.scope; F.modular = 1; F.rev = 0;
-    F.pb = sg.pb; F.pe = sg.pe; F.tb = sg.tb; F.te = sg.te;
-    F.plen = sg.pe - sg.pb; F.tlen = sg.te - sg.tb; F.shift = F.plen + 1; F.begin = sg.cb;
-    R = F;
-    R.base = ring + (size_t)a.ring_scope * 5 * (size_t)a.ring_cap;
-    R.rev = 1; R.begin = sg.ce;
+    dir_ring(F, ring, a, pen);
+    dir_ring(R, ring + a.ring_dir_stride, a, pen);
+    dir_seg(F, sg); dir_seg(R, sg);
+    F.rev = 0; R.rev = 1; F.begin = sg.cb; R.begin = sg.ce;
+    F.shift = F.plen + 1; R.shift = R.plen + 1;
     const int plen = F.plen, tlen = F.tlen;
     const int max_antidiagonal = plen + tlen - 1;
     const int scope = pen.scope;
     const int gap_opening = TWO ? max(pen.o1, pen.o2) : pen.o1;
     const long long smax = 2LL * ((long long)pen.o1 * 2 + (long long)pen.e1 * (plen + tlen)) + 1024;
     int score_f = 0, score_r = 0;
+    int done_f = -1, done_r = -1;        // highest level computed
+    int ak_f_done = 0, ak_r_done = 0;    // max antidiagonal of level done_f / done_r
     if (tid == 0) sh.bp_score = INT_MAX;
-    wf_step<OT, TWO>(F, pen, 0, P, T, -1, sh, ev, cells);
-    __syncthreads();
-    int f_max_ak = sh.red_maxak[ev % 3];
-    if (tid == 0) sh.mak[0][0] = f_max_ak;
-    ev++;
-    wf_step<OT, TWO>(R, pen, 0, P, T, -1, sh, ev, cells);
-    __syncthreads();
-    int r_max_ak = sh.red_maxak[ev % 3];
-    if (tid == 0) sh.mak[1][0] = r_max_ak;
-    ev++;
-    steps += 2;
+    STEP_BOTH(true, true);
+    int f_max_ak = ak_f_done, r_max_ak = ak_r_done;
     bool last_wf_forward = false;
     bool ok = true;
     for (;;) {
         if (f_max_ak + r_max_ak >= max_antidiagonal) break;
         ++score_f;
-        wf_step<OT, TWO>(F, pen, score_f, P, T, -1, sh, ev, cells);
-        __syncthreads();
-        f_max_ak = sh.red_maxak[ev % 3];
-        if (tid == 0) sh.mak[0][score_f % scope] = f_max_ak;
-        ev++; steps++;
+        if (done_f < score_f) STEP_BOTH(true, done_r < score_r + 1);
+        f_max_ak = ak_f_done;
         last_wf_forward = true;
         if (f_max_ak + r_max_ak >= max_antidiagonal) break;
         ++score_r;
-        wf_step<OT, TWO>(R, pen, score_r, P, T, -1, sh, ev, cells);
-        __syncthreads();
-        r_max_ak = sh.red_maxak[ev % 3];
-        if (tid == 0) sh.mak[1][score_r % scope] = r_max_ak;
-        ev++; steps++;
+        if (done_r < score_r) STEP_BOTH(done_f < score_f + 1, true);
+        r_max_ak = ak_r_done;
         last_wf_forward = false;
         if ((long long)score_f + score_r > smax) { ok = false; break; }
     }
-    __syncthreads();   // mak[] / bp_score visible to everyone
     while (ok) {
         if (last_wf_forward) {
             const int min_score_r = (score_r > scope - 1) ? score_r - (scope - 1) : 0;
-            if (score_f + min_score_r - gap_opening >= sh.bp_score) break;
-            bi_overlap<OT, TWO>(F, R, 0, 1, pen, score_f, score_r, true, sh);
+            __syncthreads();
+            if (score_f + min_score_r - gap_opening >= RFL(sh.bp_score)) break;
+            bi_overlap<OT, TWO, NT>(F, R, 0, 1, pen, score_f, score_r, true, sh);
             ++score_r;
-            wf_step<OT, TWO>(R, pen, score_r, P, T, -1, sh, ev, cells);
-            __syncthreads();
-            r_max_ak = sh.red_maxak[ev % 3];
-            if (tid == 0) sh.mak[1][score_r % scope] = r_max_ak;
-            ev++; steps++;
-            __syncthreads();
+            if (done_r < score_r) STEP_BOTH(done_f < score_f + 1, true);
         }
         const int min_score_f = (score_f > scope - 1) ? score_f - (scope - 1) : 0;
-        if (min_score_f + score_r - gap_opening >= sh.bp_score) break;
-        bi_overlap<OT, TWO>(R, F, 1, 0, pen, score_r, score_f, false, sh);
+        __syncthreads();
+        if (min_score_f + score_r - gap_opening >= RFL(sh.bp_score)) break;
+        bi_overlap<OT, TWO, NT>(R, F, 1, 0, pen, score_r, score_f, false, sh);
         ++score_f;
-        wf_step<OT, TWO>(F, pen, score_f, P, T, -1, sh, ev, cells);
-        __syncthreads();
-        f_max_ak = sh.red_maxak[ev % 3];
-        if (tid == 0) sh.mak[0][score_f % scope] = f_max_ak;
-        ev++; steps++;
-        __syncthreads();
+        if (done_f < score_f) STEP_BOTH(true, done_r < score_r + 1);
         last_wf_forward = true;
         if ((long long)score_f + score_r > smax) { ok = false; break; }
     }
     __syncthreads();
-    if (ok && sh.bp_score == INT_MAX) ok = false;
+    if (ok && RFL(sh.bp_score) == INT_MAX) ok = false;
     if (!ok && tid == 0) sh.err |= SR_DEV_ERR_SCORE_BOUND;
     __syncthreads();
     return ok;
@@ -505,20 +581,22 @@ __device__ bool find_breakpoint(const Seg &sg, const SrAlignArgs &a, const SrPen
 
 // score-only end-to-end WFA (orientation check); returns INT_MAX when the
 // score exceeds max_score (max_score < 0: unbounded)
-template <typename OT>
-__device__ int wfa_score_only(int plen, int tlen, const SrAlignArgs &a, const SrPen &pen, OT *ring,
-                              const uint32_t *P, const uint32_t *T, int max_score, Shared &sh,
+template <typename OT, int NT>
+__device__ __forceinline__ int wfa_score_only(int plen, int tlen, const SrAlignArgs &a, const SrPen &pen, GP<OT> ring,
+                              LP P, LP T, int max_score, Shared &sh,
                               int &ev, unsigned long long &cells, unsigned long long &steps) {
     Dir<OT> d;
-    d.base = ring; d.cap = a.ring_cap; d.nslots = pen.scope; d.modular = 1; d.rev = 0;
+    dir_ring(d, ring, a, pen);
+    d.cold = nullptr;                      // no breakpoint detection here: no history
+    d.rev = 0;
     d.pb = 0; d.pe = plen; d.tb = 0; d.te = tlen; d.plen = plen; d.tlen = tlen;
     d.shift = plen + 1; d.begin = SR_C_M;
     const long long smax = (long long)pen.o1 * 2 + (long long)pen.e1 * (plen + tlen) + 64;
     int s = 0, res = INT_MAX;
     for (;;) {
-        wf_step<OT, false>(d, pen, s, P, T, SR_C_M, sh, ev, cells);
+        wf_step<OT, false, NT>(d, pen, s, P, T, SR_C_M, sh, ev, 0, cells);
         __syncthreads();
-        const bool r = sh.reached[ev % 3] != 0;
+        const bool r = sh.reached[ev % 3][0] != 0;
         ev++; steps++;
         if (r) { res = s; break; }
         if (s > smax) { if (threadIdx.x == 0) sh.err |= SR_DEV_ERR_SCORE_BOUND; break; }
@@ -529,47 +607,48 @@ __device__ int wfa_score_only(int plen, int tlen, const SrAlignArgs &a, const Sr
     return res;
 }
 
-__device__ __forceinline__ void load_seq_lds(uint32_t *dst, const uint32_t *src, int nwords_with_pad) {
-    for (int i = threadIdx.x; i < nwords_with_pad; i += WG) dst[i] = src[i];
+template <int NT>
+__device__ __forceinline__ void load_seq_lds(uint32_t *dst, GP<const uint32_t> src, int nwords_with_pad) {
+    for (int i = threadIdx.x; i < nwords_with_pad; i += NT) dst[i] = src[i];
 }
 
-template <typename OT>
-__global__ void __launch_bounds__(WG) sr_align_kernel(SrAlignArgs a) {
+template <typename OT, int NT, bool TWO>
+__global__ void __launch_bounds__(NT) sr_align_kernel(SrAlignArgs a) {
     extern __shared__ uint32_t lds_seq[];     // 3 regions of max_words: P fwd, P rc, T
     __shared__ Shared sh;
     const int tid = threadIdx.x;
-    OT *ring = (OT *)a.ring + (size_t)blockIdx.x * a.ring_wg_stride;
-    OT *hist = (OT *)a.hist + (size_t)blockIdx.x * a.hist_wg_stride;
+    GP<OT> ring = (GP<OT>)(OT *)a.ring + (size_t)blockIdx.x * a.ring_wg_stride;
+    GP<OT> hist = (GP<OT>)(OT *)a.hist + (size_t)blockIdx.x * a.hist_wg_stride;
     unsigned long long cells = 0, steps = 0, nbase = 0, nbp = 0;
     int ev = 0;
     for (;;) {
         if (tid == 0) {
             sh.pair = (int)atomicAdd(a.queue_head, 1u);
             sh.err = 0; sh.sp = 0; sh.cig_cnt = 0; sh.score_acc = 0;
-            for (int i = 0; i < 3; i++) { sh.red_maxak[i] = 0; sh.reached[i] = 0; }
+            for (int i = 0; i < 3; i++) { sh.red_maxak[i][0] = sh.red_maxak[i][1] = 0; sh.reached[i][0] = sh.reached[i][1] = 0; }
         }
         __syncthreads();
-        const int pair = sh.pair;
+        const int pair = RFL(sh.pair);
         if (pair >= (int)a.npairs) break;
         const uint32_t q = a.pair_q[pair], t = a.pair_t[pair];
         const int plen = (int)a.seqlen[q], tlen = (int)a.seqlen[t];
         const int pw = ((plen + 15) >> 4) + 2, tw = ((tlen + 15) >> 4) + 2;
         uint32_t *Pf = lds_seq, *Pr = lds_seq + a.max_words, *Tt = lds_seq + 2 * (size_t)a.max_words;
-        load_seq_lds(Pf, a.seqwords + a.word_off_fwd[q] - 1, pw);
-        load_seq_lds(Pr, a.seqwords + a.word_off_rc[q] - 1, pw);
-        load_seq_lds(Tt, a.seqwords + a.word_off_fwd[t] - 1, tw);
+        load_seq_lds<NT>(Pf, (GP<const uint32_t>)a.seqwords + a.word_off_fwd[q] - 1, pw);
+        load_seq_lds<NT>(Pr, (GP<const uint32_t>)a.seqwords + a.word_off_rc[q] - 1, pw);
+        load_seq_lds<NT>(Tt, (GP<const uint32_t>)a.seqwords + a.word_off_fwd[t] - 1, tw);
         __syncthreads();
-        const uint32_t *T = Tt + 1;
+        const LP T = (LP)(Tt + 1);
         // ---- orientation (forward on ties; reverse scored only up to fwd-1)
-        const int fwd = wfa_score_only<OT>(plen, tlen, a, a.ori, ring, Pf + 1, T, -1, sh, ev, cells, steps);
+        const int fwd = wfa_score_only<OT, NT>(plen, tlen, a, a.ori, ring, (LP)(Pf + 1), T, -1, sh, ev, cells, steps);
         int rev = INT_MAX;
         bool is_rev = false;
         if (fwd > 0 && fwd != INT_MAX) {
-            rev = wfa_score_only<OT>(plen, tlen, a, a.ori, ring, Pr + 1, T, fwd - 1, sh, ev, cells, steps);
+            rev = wfa_score_only<OT, NT>(plen, tlen, a, a.ori, ring, (LP)(Pr + 1), T, fwd - 1, sh, ev, cells, steps);
             is_rev = rev < fwd;
         }
-        const uint32_t *P = (is_rev ? Pr : Pf) + 1;
-        uint32_t *ops = a.cigar_ops + a.cigar_base[pair];
+        const LP P = (LP)((is_rev ? Pr : Pf) + 1);
+        GP<uint32_t> ops = (GP<uint32_t>)a.cigar_ops + a.cigar_base[pair];
         const uint32_t cap = (uint32_t)(a.cigar_base[pair + 1] - a.cigar_base[pair]);
         // ---- main alignment
         if (tid == 0) {
@@ -578,10 +657,15 @@ __global__ void __launch_bounds__(WG) sr_align_kernel(SrAlignArgs a) {
             sh.stack[0] = s0; sh.sp = 1;
         }
         __syncthreads();
-        while (sh.sp > 0 && sh.err == 0) {
-            const Seg sg = sh.stack[sh.sp - 1];
+        while (RFL(sh.sp) > 0 && RFL(sh.err) == 0) {
+            const int top = RFL(sh.sp) - 1;
+            Seg sg;
+            sg.pb = RFL(sh.stack[top].pb); sg.pe = RFL(sh.stack[top].pe);
+            sg.tb = RFL(sh.stack[top].tb); sg.te = RFL(sh.stack[top].te);
+            sg.cb = RFL(sh.stack[top].cb); sg.ce = RFL(sh.stack[top].ce);
+            sg.score_rem = RFL(sh.stack[top].score_rem);
             __syncthreads();
-            if (tid == 0) sh.sp--;
+            if (tid == 0) sh.sp = top;
             const int sp_len = sg.pe - sg.pb, st_len = sg.te - sg.tb;
             if (st_len == 0 || sp_len == 0) {
                 if (tid == 0) {
@@ -596,14 +680,11 @@ __global__ void __launch_bounds__(WG) sr_align_kernel(SrAlignArgs a) {
             const bool base = sg.score_rem <= 250 || max(sp_len, st_len) <= 100;
             if (base) {
                 nbase++;
-                if (a.pen.two) wfa_base<OT, true>(sg, a, a.pen, hist, P, T, sh, ev, cells, steps, ops, cap);
-                else wfa_base<OT, false>(sg, a, a.pen, hist, P, T, sh, ev, cells, steps, ops, cap);
+                wfa_base<OT, TWO, NT>(sg, a, a.pen, hist, P, T, sh, ev, cells, steps, ops, cap);
                 continue;
             }
             nbp++;
-            bool ok;
-            if (a.pen.two) ok = find_breakpoint<OT, true>(sg, a, a.pen, ring, P, T, sh, ev, cells, steps);
-            else ok = find_breakpoint<OT, false>(sg, a, a.pen, ring, P, T, sh, ev, cells, steps);
+            const bool ok = find_breakpoint<OT, TWO, NT>(sg, a, a.pen, ring, P, T, sh, ev, cells, steps);
             if (ok && tid == 0) {
                 const int bh = sh.bp_off_f, bv = sh.bp_off_f - sh.bp_k_f;
                 if (bv < 0 || bv > sp_len || bh < 0 || bh > st_len) sh.err |= SR_DEV_ERR_BREAKPOINT;
@@ -620,14 +701,14 @@ __global__ void __launch_bounds__(WG) sr_align_kernel(SrAlignArgs a) {
         }
         __syncthreads();
         // ---- score of the final CIGAR (gaps costed once per merged run)
-        const uint32_t cnt = sh.cig_cnt;
+        const uint32_t cnt = RFL(sh.cig_cnt);
         int part = 0;
-        for (uint32_t i = tid; i < cnt; i += WG) {
+        for (uint32_t i = tid; i < cnt; i += NT) {
             const uint32_t op = ops[i] & 15u; const int len = (int)(ops[i] >> 4);
             if (op == SR_OP_X) part += len * a.pen.x;
             else if (op == SR_OP_I || op == SR_OP_D) {
                 int g = a.pen.o1 + a.pen.e1 * len;
-                if (a.pen.two) g = min(g, a.pen.o2 + a.pen.e2 * len);
+                if (TWO) g = min(g, a.pen.o2 + a.pen.e2 * len);
                 part += g;
             }
         }
@@ -844,25 +925,30 @@ __global__ void sr_merge_kernel(unsigned long long *nodes, unsigned long long n,
 // ------------------------------------------------------------------ launchers
 extern "C" int srk_align_max_lds(void) { return 160 * 1024 - (int)sizeof(Shared) - 1024; }
 
-extern "C" int srk_align(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, void *stream) {
-    hipStream_t st = (hipStream_t)stream;
-    hipError_t e;
-    if (off16) {
-        if (lds_bytes > 48 * 1024) {
-            e = hipFuncSetAttribute((const void *)sr_align_kernel<int16_t>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-            if (e != hipSuccess) return (int)e;
-        }
-        hipLaunchKernelGGL(sr_align_kernel<int16_t>, dim3(nwg), dim3(WG), lds_bytes, st, *a);
-    } else {
-        if (lds_bytes > 48 * 1024) {
-            e = hipFuncSetAttribute((const void *)sr_align_kernel<int32_t>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-            if (e != hipSuccess) return (int)e;
-        }
-        hipLaunchKernelGGL(sr_align_kernel<int32_t>, dim3(nwg), dim3(WG), lds_bytes, st, *a);
+template <typename OT, int NT, bool TWO>
+static int launch_align3(const SrAlignArgs *a, int nwg, size_t lds_bytes, hipStream_t st) {
+    if (lds_bytes > 32 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)sr_align_kernel<OT, NT, TWO>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return (int)e;
     }
+    hipLaunchKernelGGL((sr_align_kernel<OT, NT, TWO>), dim3(nwg), dim3(NT), lds_bytes, st, *a);
     return (int)hipGetLastError();
+}
+template <typename OT, int NT>
+static int launch_align(const SrAlignArgs *a, int nwg, size_t lds_bytes, hipStream_t st) {
+    return a->pen.two ? launch_align3<OT, NT, true>(a, nwg, lds_bytes, st)
+                      : launch_align3<OT, NT, false>(a, nwg, lds_bytes, st);
+}
+
+extern "C" int srk_align(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, int nthreads, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (off16) {
+        if (nthreads == 512) return launch_align<int16_t, 512>(a, nwg, lds_bytes, st);
+        return launch_align<int16_t, 256>(a, nwg, lds_bytes, st);
+    }
+    if (nthreads == 512) return launch_align<int32_t, 512>(a, nwg, lds_bytes, st);
+    return launch_align<int32_t, 256>(a, nwg, lds_bytes, st);
 }
 
 extern "C" int srk_unite(const SrUniteArgs *a, int nwg, void *stream) {

@@ -158,7 +158,7 @@ struct sr_ctx {
     std::vector<uint32_t> pair_q, pair_t;
     std::vector<uint64_t> cigar_base;
     uint64_t dp_cells = 0;
-    int off16 = 1, nwg = 0;
+    int off16 = 1, nwg = 0, nthreads = 256;
     size_t lds_bytes = 0;
     SrAlignArgs aa{};
     SrUniteArgs ua{};
@@ -292,7 +292,7 @@ static int make_pen(const sr_params &p, bool ori, SrPen *out) {
     out->scope = std::max(out->x, out->o1 + out->e1);
     if (out->two) out->scope = std::max(out->scope, out->o2 + out->e2);
     out->scope += 1;
-    if (out->scope > SR_MAX_SCOPE) return fail(SR_ERR_UNSUPPORTED, "penalties too large for the device ring (scope > 128)");
+    if (out->scope > SR_MAX_SCOPE) return fail(SR_ERR_UNSUPPORTED, "penalties too large for the device ring (scope > 127)");
     return SR_OK;
 }
 
@@ -374,11 +374,17 @@ extern "C" int sr_ctx_load(sr_ctx *c, const sr_seqset *seqs, const sr_params *p)
         return fail(SR_ERR_UNSUPPORTED, "sequences too long to stage in LDS (limit ~ 200 kb per sequence)");
     int wg_per_cu = 4;
     if (const char *e = getenv("SR_WG_PER_CU")) wg_per_cu = std::max(1, atoi(e));
+    c->nthreads = 256;
+    if (const char *e = getenv("SR_ALIGN_THREADS")) { int v = atoi(e); if (v == 256 || v == 512 || v == 1024) c->nthreads = v; }
     const size_t lds_per_wg = c->lds_bytes + 16 * 1024;
     wg_per_cu = (int)std::min<size_t>((size_t)wg_per_cu, std::max<size_t>(1, (160 * 1024) / lds_per_wg));
     const int ring_scope = std::max(pen.scope, ori.scope);
     const int ring_cap = (int)((2 * maxlen + 3 + 7) & ~7ULL);
-    const uint64_t ring_wg = 2ULL * ring_scope * 5 * (uint64_t)ring_cap;
+    int emax = std::max(pen.e1, ori.e1);
+    if (pen.two) emax = std::max(emax, pen.e2);
+    const int ring_hot = emax + 2;
+    const uint64_t ring_dir = ((uint64_t)(ring_scope + 1) + 4ULL * ring_hot + 4ULL * (ring_scope + 1)) * (uint64_t)ring_cap;
+    const uint64_t ring_wg = 2ULL * ring_dir;
     const int gapmax = pen.two ? std::max(pen.o1, pen.o2) : pen.o1;
     auto gc = [&](int len) { int g = pen.o1 + pen.e1 * len; if (pen.two) g = std::min(g, pen.o2 + pen.e2 * len); return g; };
     const int smax_base = std::max(250 + gapmax, 2 * gc(100)) + 2 * gapmax + 4;
@@ -441,7 +447,7 @@ extern "C" int sr_ctx_load(sr_ctx *c, const sr_seqset *seqs, const sr_params *p)
     a.seqwords = d_words; a.word_off_fwd = d_wf; a.word_off_rc = d_wr; a.seqlen = d_len;
     a.max_words = max_words; a.pair_q = d_pq; a.pair_t = d_pt; a.npairs = np;
     a.queue_head = c->d_queue; a.pen = pen; a.ori = ori; a.mem_mode = p->memory_mode;
-    a.ring_wg_stride = ring_wg; a.ring_cap = ring_cap; a.ring_scope = ring_scope;
+    a.ring_wg_stride = ring_wg; a.ring_dir_stride = ring_dir; a.ring_cap = ring_cap; a.ring_scope = ring_scope; a.ring_hot = ring_hot;
     a.hist_wg_stride = hist_wg; a.hist_w = hist_w; a.hist_levels = hist_levels;
     a.cigar_base = d_cbase; a.counters = c->d_counters; a.error_flag = c->d_error;
     SrUniteArgs &u = c->ua;
@@ -472,7 +478,7 @@ extern "C" int sr_ctx_align(sr_ctx *c) {
     HIPCHK(hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
     HIPCHK(hipEventRecord(c->ev[0][0], c->stream));
     if (c->aa.npairs > 0) {
-        int r = srk_align(&c->aa, c->nwg, c->lds_bytes, c->off16, c->stream);
+        int r = srk_align(&c->aa, c->nwg, c->lds_bytes, c->off16, c->nthreads, c->stream);
         if (r) return fail(SR_ERR_HIP, std::string("align kernel launch failed: ") + hipGetErrorString((hipError_t)r));
     }
     HIPCHK(hipEventRecord(c->ev[0][1], c->stream));

@@ -5,7 +5,7 @@
 #include <stddef.h>
 
 #define SR_NULL_OFF (-8192)          // null wavefront offset (fits int16)
-#define SR_MAX_SCOPE 128             // max ring depth supported on device
+#define SR_MAX_SCOPE 127             // max ring depth supported on device
 #define SR_STACK_DEPTH 64
 #define SR_WG 256                    // threads per workgroup (4 waves of 64)
 
@@ -45,10 +45,13 @@ struct SrAlignArgs {
     SrPen pen, ori;
     int mem_mode;
     // per-workgroup workspace
-    void *ring;                // [nwg][2][scope_max][5][ring_cap] offsets
+    void *ring;                // per WG: 2 directions x { M[(ring_scope+1)] | I1 I2 D1 D2 hot [ring_hot] each |
+                               //   cold I/D history [(ring_scope+1)][4] } rows of ring_cap offsets
     uint64_t ring_wg_stride;   // elements per workgroup
+    uint64_t ring_dir_stride;  // elements per direction
     int ring_cap;
-    int ring_scope;            // slots allocated per direction
+    int ring_scope;            // max scope over both penalty sets
+    int ring_hot;              // hot I/D rows per component (max gap-extend + 2)
     void *hist;                // [nwg][hist_levels][5][hist_w]
     uint64_t hist_wg_stride;
     int hist_w, hist_levels;
@@ -85,7 +88,7 @@ struct SrUniteArgs {
 extern "C" {
 #endif
 // launchers implemented in sr_device.hip (hipStream_t passed as void*)
-int srk_align(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, void *stream);
+int srk_align(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, int nthreads, void *stream);
 int srk_unite(const SrUniteArgs *a, int nwg, void *stream);
 int srk_uf_init(unsigned long long *nodes, uint64_t total_len, uint64_t uf_size, void *stream);
 int srk_labels(unsigned long long *nodes, uint64_t uf_size, unsigned long long *minarr,
