@@ -53,7 +53,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--nseq", type=int, default=64)
-    ap.add_argument("--cpu-sample-pairs", type=int, default=256)
+    ap.add_argument("--cpu-sample-pairs", type=int, default=0,
+                    help="pairs in the CPU-baseline sample (0 = 8 per host core, at least 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -170,7 +171,9 @@ def main():
             "kernels": cnt,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(recs, min(args.cpu_sample_pairs, total_pairs))
+            ncore = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            sample = args.cpu_sample_pairs or max(256, 8 * ncore)
+            out["cpu_baseline"] = cpu_baseline(recs, min(sample, total_pairs))
     ctx.close()
     if world > 1:
         dist.barrier()

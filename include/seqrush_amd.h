@@ -166,8 +166,10 @@ int sr_ctx_download_labels(sr_ctx *c, uint64_t *labels_out);
 int sr_ctx_kernel_ms(sr_ctx *c, int which, float *ms);
 /* device counters accumulated by the last align: [0] wavefront cells,
  * [1] wavefront steps, [2] base-case segments, [3] breakpoint searches,
- * [4] united bases (after unite), [5] match runs */
-int sr_ctx_counters(sr_ctx *c, uint64_t out[8]);
+ * [4] united bases (after unite), [5] match runs, [6..10] 100 MHz ticks summed
+ * over workgroups: orientation, breakpoint search, base cases, top-level
+ * breakpoint search, whole pair */
+int sr_ctx_counters(sr_ctx *c, uint64_t out[16]);
 
 /* -------- consumer (A9): graph induction + GFA, host C++ -----------------
  * build_bidirected_graph_with_options (bidirected_builder.rs:17-289) +

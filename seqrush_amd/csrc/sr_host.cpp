@@ -372,18 +372,19 @@ extern "C" int sr_ctx_load(sr_ctx *c, const sr_seqset *seqs, const sr_params *p)
     c->lds_bytes = (size_t)max_words * 3 * 4;
     if ((long long)c->lds_bytes > (long long)srk_align_max_lds())
         return fail(SR_ERR_UNSUPPORTED, "sequences too long to stage in LDS (limit ~ 200 kb per sequence)");
-    int wg_per_cu = 4;
+    int wg_per_cu = 8;
     if (const char *e = getenv("SR_WG_PER_CU")) wg_per_cu = std::max(1, atoi(e));
-    c->nthreads = 256;
-    if (const char *e = getenv("SR_ALIGN_THREADS")) { int v = atoi(e); if (v == 256 || v == 512 || v == 1024) c->nthreads = v; }
-    const size_t lds_per_wg = c->lds_bytes + 16 * 1024;
+    c->nthreads = 128;
+    if (const char *e = getenv("SR_ALIGN_THREADS")) { int v = atoi(e); if (v == 64 || v == 128 || v == 256) c->nthreads = v; }
+    const size_t lds_per_wg = c->lds_bytes + 8 * 1024;
     wg_per_cu = (int)std::min<size_t>((size_t)wg_per_cu, std::max<size_t>(1, (160 * 1024) / lds_per_wg));
     const int ring_scope = std::max(pen.scope, ori.scope);
     const int ring_cap = (int)((2 * maxlen + 3 + 7) & ~7ULL);
     int emax = std::max(pen.e1, ori.e1);
     if (pen.two) emax = std::max(emax, pen.e2);
     const int ring_hot = emax + 2;
-    const uint64_t ring_dir = ((uint64_t)(ring_scope + 1) + 4ULL * ring_hot + 4ULL * (ring_scope + 1)) * (uint64_t)ring_cap;
+    // M ring | 4 hot I/D rings | cold I/D history | 1 NULL row
+    const uint64_t ring_dir = ((uint64_t)(ring_scope + 1) + 4ULL * ring_hot + 4ULL * (ring_scope + 1) + 1ULL) * (uint64_t)ring_cap;
     const uint64_t ring_wg = 2ULL * ring_dir;
     const int gapmax = pen.two ? std::max(pen.o1, pen.o2) : pen.o1;
     auto gc = [&](int len) { int g = pen.o1 + pen.e1 * len; if (pen.two) g = std::min(g, pen.o2 + pen.e2 * len); return g; };
@@ -391,8 +392,8 @@ extern "C" int sr_ctx_load(sr_ctx *c, const sr_seqset *seqs, const sr_params *p)
     const int hist_levels = smax_base + 1;
     int rmax = smax_base / pen.e1;
     if (pen.two) rmax = std::max(rmax, smax_base / pen.e2);
-    const int hist_w = (2 * (rmax + pen.scope + 2) + 1 + 7) & ~7;
-    const uint64_t hist_wg = (uint64_t)hist_levels * 5 * (uint64_t)hist_w;
+    const int hist_w = (2 * (rmax + pen.scope + 2) + 1 + 8 + 7) & ~7;   // rows hold whole 4-diagonal groups
+    const uint64_t hist_wg = (uint64_t)hist_levels * 5 * (uint64_t)hist_w + (uint64_t)hist_w;   // + NULL row
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
     const uint64_t per_wg_bytes = (ring_wg + hist_wg) * osz;
@@ -435,12 +436,12 @@ extern "C" int sr_ctx_load(sr_ctx *c, const sr_seqset *seqs, const sr_params *p)
     if ((r = dev_alloc(c, &d, ((size_t)np + 1) * 4))) return r; a.ori_rev = (int32_t *)d;
     if ((r = dev_alloc(c, &d, ((size_t)np + 1) * 4))) return r; a.cigar_cnt = (uint32_t *)d;
     if ((r = dev_alloc(c, &d, (c->cigar_base[np] + 1) * 4))) return r; a.cigar_ops = (uint32_t *)d;
-    if ((r = dev_alloc(c, &d, 8 * sizeof(unsigned long long)))) return r; c->d_counters = (unsigned long long *)d;
+    if ((r = dev_alloc(c, &d, 16 * sizeof(unsigned long long)))) return r; c->d_counters = (unsigned long long *)d;
     if ((r = dev_alloc(c, &d, sizeof(int)))) return r; c->d_error = (int *)d;
     if ((r = dev_alloc(c, &d, c->uf_size * 8))) return r; c->d_nodes = (unsigned long long *)d;
     if ((r = dev_alloc(c, &d, c->uf_size * 8))) return r; c->d_minarr = (unsigned long long *)d;
     if ((r = dev_alloc(c, &d, c->uf_size * 8))) return r; c->d_labels = (unsigned long long *)d;
-    HIPCHK(hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
+    HIPCHK(hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream));
     HIPCHK(hipMemsetAsync(c->d_error, 0, sizeof(int), c->stream));
     HIPCHK(hipMemsetAsync(a.cigar_cnt, 0, ((size_t)np + 1) * 4, c->stream));
     HIPCHK(hipMemsetAsync(a.score, 0xff, ((size_t)np + 1) * 4, c->stream));
@@ -475,7 +476,7 @@ extern "C" int sr_ctx_align(sr_ctx *c) {
     if (!c || !c->loaded) return fail(SR_ERR_INVALID, "context not loaded");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemsetAsync(c->d_queue, 0, sizeof(uint32_t), c->stream));
-    HIPCHK(hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
+    HIPCHK(hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream));
     HIPCHK(hipEventRecord(c->ev[0][0], c->stream));
     if (c->aa.npairs > 0) {
         int r = srk_align(&c->aa, c->nwg, c->lds_bytes, c->off16, c->nthreads, c->stream);
@@ -527,11 +528,11 @@ extern "C" int sr_ctx_kernel_ms(sr_ctx *c, int which, float *ms) {
     return SR_OK;
 }
 
-extern "C" int sr_ctx_counters(sr_ctx *c, uint64_t out[8]) {
+extern "C" int sr_ctx_counters(sr_ctx *c, uint64_t out[16]) {
     if (!c || !c->loaded) return fail(SR_ERR_INVALID, "context not loaded");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemcpy(out, c->d_counters, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out, c->d_counters, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return SR_OK;
 }
 
