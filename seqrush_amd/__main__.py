@@ -1,0 +1,42 @@
+"""`python -m seqrush_amd` -- thin CLI with the reference's flag surface for the hot path
+(src/seqrush.rs:17-152, src/main.rs:4-7).  Everything that computes runs on the GPU."""
+import argparse
+import sys
+
+from .seqrush import Args, run_seqrush
+from ._lib import SeqRushError
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="seqrush", description="MI355X-native seqrush hot path")
+    ap.add_argument("-s", "--sequences", required=True)
+    ap.add_argument("-o", "--output", default="output.gfa")
+    ap.add_argument("-k", "--min-match-length", type=int, default=0)
+    ap.add_argument("-t", "--threads", type=int, default=4)
+    ap.add_argument("-S", "--scores", default="0,5,8,2,24,1")
+    ap.add_argument("--orientation-scores", default="0,1,1,1")
+    ap.add_argument("-d", "--max-divergence", type=float, default=None)
+    ap.add_argument("-x", "--sparsify", dest="sparsification", default="none")
+    ap.add_argument("-p", "--paf", default=None)
+    ap.add_argument("--output-alignments", default=None)
+    ap.add_argument("--no-compact", action="store_true")
+    ap.add_argument("--no-sort", action="store_true")
+    ap.add_argument("--aligner", default="allwave")
+    ap.add_argument("-v", "--verbose", action="store_true")
+    ap.add_argument("--device", type=int, default=0)
+    ns = ap.parse_args(argv)
+    args = Args(sequences=ns.sequences, output=ns.output, min_match_length=ns.min_match_length,
+                threads=ns.threads, scores=ns.scores, orientation_scores=ns.orientation_scores,
+                max_divergence=ns.max_divergence, sparsification=ns.sparsification, paf=ns.paf,
+                output_alignments=ns.output_alignments, no_compact=ns.no_compact, no_sort=ns.no_sort,
+                aligner=ns.aligner, verbose=ns.verbose, device=ns.device)
+    try:
+        run_seqrush(args)
+    except (SeqRushError, ValueError) as e:
+        print(f"Error: {e}", file=sys.stderr)
+        return 1
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -272,3 +272,27 @@ def test_full_size_c2_properties(gpu):
             f = l.split("\t")
             assert "".join(seg[s[:-1]] for s in f[2].split(",")) == dict(recs)[f[1]].decode()
     assert nn < len(bases)
+
+
+def test_run_seqrush_cli_end_to_end(gpu, tmp_path, capsys):
+    """run_seqrush (src/seqrush.rs:1839-1853) through the CLI mirror: stdout lines and GFA"""
+    from seqrush_amd.__main__ import main
+    recs = synth.snp_family(4, 300, 0.05, 95)
+    fa = tmp_path / "in.fa"
+    fa.write_bytes(b"".join(b">" + n.encode() + b" some description\n" + s[:120] + b"\n" + s[120:] + b"\n" for n, s in recs))
+    out = tmp_path / "out.gfa"
+    paf = tmp_path / "aln.paf"
+    rc = main(["-s", str(fa), "-o", str(out), "-k", "0", "--no-sort", "--no-compact", "--output-alignments", str(paf)])
+    assert rc == 0
+    text = capsys.readouterr().out
+    assert "Loaded 4 sequences" in text and "Building graph with 4 sequences (total length: 1200)" in text
+    assert "Total sequence pairs: 16" in text and f"Graph written to {out}" in text
+    o = ob.OracleSeqRush(records=recs)
+    o.align_and_unite(ob.default_params())
+    assert canon_gfa(out.read_text()) == canon_gfa(o.gfa(canonical=True)[0])
+    assert len(paf.read_text().strip().split("\n")) == 16
+    # default pipeline (compaction + Ygs sort) is outside the hot path: loud error, not a silent skip
+    assert main(["-s", str(fa), "-o", str(out)]) == 1
+    empty = tmp_path / "e.fa"
+    empty.write_bytes(b">a\nACGT\n>b\n\n")
+    assert main(["-s", str(empty), "-o", str(out), "--no-sort", "--no-compact"]) == 1
