@@ -37,7 +37,9 @@ struct DirL {
     int nsm, nsg1, nsg2, nsc;
     int cap, shift, modular, rev;
     int pb, pe, tb, te, plen, tlen, begin;
-    int lvl, sm, sg1, sg2, sc;                   // last computed level and its ring slots
+    // last computed level and its ring slots, double-buffered by step parity: a step reads
+    // copy [ev & 1] while thread 0 writes copy [(ev + 1) & 1] (no wave can see a half update)
+    int lvl[2], sm[2], sg1[2], sg2[2], sc[2];
 };
 
 struct Shared {
@@ -89,7 +91,7 @@ struct Dir {
 };
 
 template <typename OT>
-__device__ __forceinline__ Dir<OT> load_dir(int i) {
+__device__ __forceinline__ Dir<OT> load_dir(int i, int par = 0) {
     const DirL &l = g_sh.dl[i];
     Dir<OT> d;
     d.m = (GP<OT>)rfl64(l.m);
@@ -99,7 +101,7 @@ __device__ __forceinline__ Dir<OT> load_dir(int i) {
     d.cap = RFL(l.cap); d.shift = RFL(l.shift); d.modular = RFL(l.modular); d.rev = RFL(l.rev);
     d.pb = RFL(l.pb); d.pe = RFL(l.pe); d.tb = RFL(l.tb); d.te = RFL(l.te);
     d.plen = RFL(l.plen); d.tlen = RFL(l.tlen); d.begin = RFL(l.begin);
-    d.lvl = RFL(l.lvl); d.sm = RFL(l.sm); d.sg1 = RFL(l.sg1); d.sg2 = RFL(l.sg2); d.sc = RFL(l.sc);
+    d.lvl = RFL(l.lvl[par]); d.sm = RFL(l.sm[par]); d.sg1 = RFL(l.sg1[par]); d.sg2 = RFL(l.sg2[par]); d.sc = RFL(l.sc[par]);
     return d;
 }
 __device__ __forceinline__ SrPen load_pen(int sel) {
@@ -113,17 +115,23 @@ __device__ __forceinline__ SrPen load_pen(int sel) {
 __device__ __forceinline__ int slot_inc(int v, int n) { return (v + 1 == n) ? 0 : v + 1; }
 __device__ __forceinline__ int slot_back(int v, int delta, int n) { const int w = v - delta; return w < 0 ? w + n : w; }
 
-// thread 0: level lvl+1 of aligner i has been computed
-__device__ __forceinline__ void dirl_advance(int i) {
+// thread 0: publish the running state for the next step (parity np = (ev + 1) & 1);
+// `stepped` = level lvl+1 of aligner i has just been computed
+__device__ __forceinline__ void dirl_advance(int i, int par, bool stepped) {
     DirL &l = g_sh.dl[i];
-    l.lvl++;
-    if (l.modular) {
-        l.sm = slot_inc(l.sm, l.nsm); l.sg1 = slot_inc(l.sg1, l.nsg1);
-        l.sg2 = slot_inc(l.sg2, l.nsg2); l.sc = slot_inc(l.sc, l.nsc);
+    const int np = par ^ 1;
+    if (stepped) {
+        l.lvl[np] = l.lvl[par] + 1;
+        if (l.modular) {
+            l.sm[np] = slot_inc(l.sm[par], l.nsm); l.sg1[np] = slot_inc(l.sg1[par], l.nsg1);
+            l.sg2[np] = slot_inc(l.sg2[par], l.nsg2); l.sc[np] = slot_inc(l.sc[par], l.nsc);
+        } else { l.sm[np] = l.sm[par]; l.sg1[np] = l.sg1[par]; l.sg2[np] = l.sg2[par]; l.sc[np] = l.sc[par]; }
+    } else {
+        l.lvl[np] = l.lvl[par]; l.sm[np] = l.sm[par]; l.sg1[np] = l.sg1[par]; l.sg2[np] = l.sg2[par]; l.sc[np] = l.sc[par];
     }
 }
 __device__ __forceinline__ void dirl_reset(DirL &l) {
-    l.lvl = -1; l.sm = l.nsm - 1; l.sg1 = l.nsg1 - 1; l.sg2 = l.nsg2 - 1; l.sc = l.nsc - 1;
+    for (int q = 0; q < 2; q++) { l.lvl[q] = -1; l.sm[q] = l.nsm - 1; l.sg1[q] = l.nsg1 - 1; l.sg2[q] = l.nsg2 - 1; l.sc[q] = l.nsc - 1; }
 }
 
 // unshifted row of level (lvl + 1 - delta) without integer division (hot path)
@@ -401,42 +409,75 @@ __device__ __forceinline__ void step_reduce(int ev, int side, int my_ak, bool my
 }
 
 // One score step: level lvl+1 of aligner dl[0] (when do_a) and of aligner
-// dl[1] (when do_b) in the same pass.  Per batch every thread first issues the
-// source loads of its group (4 diagonals) of A and of B, then finishes them,
-// so one memory latency covers both.  Reductions (M max antidiagonal, end
-// test) go to LDS slot [ev % 3][side]; thread 0 advances the aligners' level
-// counters.  The caller's __syncthreads() publishes everything.
+// dl[1] (when do_b) in the same pass.  When both run, even waves take aligner
+// 0 and odd waves aligner 1 (the side is wave-uniform, so each wave sets up
+// and walks ONE aligner); otherwise all waves share the one aligner.  A thread
+// owns groups of 4 adjacent diagonals, two groups are in flight at a time (all
+// source loads of both are issued before either is finished).  Reductions (M
+// max antidiagonal, end test) go to LDS slot [ev % 3][side]; thread 0 advances
+// the aligners' level counters.  The caller's __syncthreads() publishes it all.
 template <typename OT, bool TWO, int NT>
 __device__ __forceinline__ void wf_step_nl(int do_a_, int chk_a_, int do_b_, int ev_, int pen_sel_) {
     const int tid = threadIdx.x;
     const bool do_a = RFL(do_a_) != 0, do_b = RFL(do_b_) != 0;
-    const int chk_a = RFL(chk_a_), ev = RFL(ev_);
+    const int ev = RFL(ev_);
     const SrPen pen = load_pen(RFL(pen_sel_));
     const LP P = (LP)(lds_seq + RFL(g_sh.offP)), T = (LP)(lds_seq + RFL(g_sh.offT));
-    StepRows<OT> ra, rb;
-    int ga0 = 0, ga1 = -1, gb0 = 0, gb1 = -1;
-    if (do_a) { const Dir<OT> A = load_dir<OT>(0); step_rows<OT, TWO>(A, pen, ra); ga0 = (ra.wlo + ra.shift) >> 2; ga1 = (ra.whi + ra.shift) >> 2; }
-    if (do_b) { const Dir<OT> B = load_dir<OT>(1); step_rows<OT, TWO>(B, pen, rb); gb0 = (rb.wlo + rb.shift) >> 2; gb1 = (rb.whi + rb.shift) >> 2; }
-    const int na = ga1 - ga0 + 1, nb = gb1 - gb0 + 1;
-    int ak_a = 0, ak_b = 0;
-    bool re_a = false, re_b = false;
-    const int nmax = max(na, nb);
-    for (int b0 = 0; b0 < nmax; b0 += NT) {
-        GroupIn<OT> ia, ib;
-        const int ga = ga0 + b0 + tid, gb = gb0 + b0 + tid;
-        const bool act_a = do_a && ga <= ga1, act_b = do_b && gb <= gb1;
-        if (act_a) group_load<OT, TWO>(ra, ga, ia);
-        if (act_b) group_load<OT, TWO>(rb, gb, ib);
-        if (act_a) group_finish<OT, TWO>(ra, ga, ia, P, T, chk_a, ak_a, re_a);
-        if (act_b) group_finish<OT, TWO>(rb, gb, ib, P, T, -1, ak_b, re_b);
+    constexpr int NW = NT / 64;
+    const int wave = RFL(tid >> 6), lane = tid & 63;
+    const bool both = do_a && do_b && NW >= 2;
+    // which aligner this wave works on, its index among the waves of that side, and their number
+    const int side = both ? (wave & 1) : (do_a ? 0 : 1);
+    const int wis = both ? (wave >> 1) : wave;
+    const int nws = both ? (NW >> 1) : NW;
+    const int chk = (side == 0) ? RFL(chk_a_) : -1;
+    if (do_a && do_b && NW < 2) {            // single-wave workgroup: the two aligners one after the other
+        for (int sd = 0; sd < 2; sd++) {
+            StepRows<OT> r;
+            const Dir<OT> D = load_dir<OT>(sd, ev & 1);
+            step_rows<OT, TWO>(D, pen, r);
+            const int g0 = (r.wlo + r.shift) >> 2, g1 = (r.whi + r.shift) >> 2;
+            int ak = 0; bool re = false;
+            for (int g = g0 + lane; g <= g1; g += 64) {
+                GroupIn<OT> in;
+                group_load<OT, TWO>(r, g, in);
+                group_finish<OT, TWO>(r, g, in, P, T, sd == 0 ? RFL(chk_a_) : -1, ak, re);
+            }
+            step_reduce(ev, sd, ak, re);
+            if (tid == 0 && r.khi >= r.klo) g_sh.cells += (unsigned long long)(r.khi - r.klo + 1);
+        }
+    } else {
+        StepRows<OT> r;
+        const Dir<OT> D = load_dir<OT>(side, ev & 1);
+        step_rows<OT, TWO>(D, pen, r);
+        const int g0 = (r.wlo + r.shift) >> 2, g1 = (r.whi + r.shift) >> 2;
+        const int stride = nws * 64;
+        int ak = 0; bool re = false;
+        for (int g = g0 + wis * 64 + lane; g <= g1; g += 2 * stride) {
+            GroupIn<OT> i0, i1;
+            const int gb = g + stride;
+            group_load<OT, TWO>(r, g, i0);
+            if (gb <= g1) group_load<OT, TWO>(r, gb, i1);
+            group_finish<OT, TWO>(r, g, i0, P, T, chk, ak, re);
+            if (gb <= g1) group_finish<OT, TWO>(r, gb, i1, P, T, chk, ak, re);
+        }
+        // every wave of a side reduces into that side's slot; waves of an idle side skip
+        if ((side == 0 && do_a) || (side == 1 && do_b)) {
+            ak = wave_max(ak);
+            const int slot = ev % 3;
+            if (lane == 0 && ak > 0) atomicMax(&g_sh.red_maxak[slot][side], ak);
+            if (re) g_sh.reached[slot][side] = 1;
+            if (lane == 0 && wis == 0 && r.khi >= r.klo)
+                atomicAdd(&g_sh.cells, (unsigned long long)(r.khi - r.klo + 1));
+        }
+        if (tid == 0) {
+            g_sh.red_maxak[(ev + 1) % 3][0] = 0; g_sh.reached[(ev + 1) % 3][0] = 0;
+            g_sh.red_maxak[(ev + 1) % 3][1] = 0; g_sh.reached[(ev + 1) % 3][1] = 0;
+        }
     }
-    if (do_a) step_reduce(ev, 0, ak_a, re_a);
-    if (do_b) step_reduce(ev, 1, ak_b, re_b);
     if (tid == 0) {
-        unsigned long long c = 0;
-        if (do_a) { dirl_advance(0); if (ra.khi >= ra.klo) c += (unsigned long long)(ra.khi - ra.klo + 1); }
-        if (do_b) { dirl_advance(1); if (rb.khi >= rb.klo) c += (unsigned long long)(rb.khi - rb.klo + 1); }
-        g_sh.cells += c;
+        dirl_advance(0, ev & 1, do_a);
+        dirl_advance(1, ev & 1, do_b);
     }
 }
 
