@@ -994,6 +994,8 @@ __global__ void __launch_bounds__(NT, SR_MIN_WAVES) sr_align_kernel(SrAlignArgs 
     }
 }
 
+#include "sr_align_bfs.inc"
+
 // ------------------------------------------------------------------ UF
 #define UF_PARENT_MASK 0x03FFFFFFFFFFFFFFULL
 #define UF_RANK_SHIFT 58
@@ -1198,14 +1200,35 @@ static int launch_align3(const SrAlignArgs *a, int nwg, size_t lds_bytes, hipStr
     hipLaunchKernelGGL((sr_align_kernel<OT, NT, TWO>), dim3(nwg), dim3(NT), lds_bytes, st, *a);
     return (int)hipGetLastError();
 }
+template <typename OT, int NT, bool TWO>
+static int launch_bfs3(const SrAlignArgs *a, int nwg, size_t lds_bytes, hipStream_t st) {
+    if (lds_bytes > 32 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)sr_align_bfs_kernel<OT, NT, TWO>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL((sr_align_bfs_kernel<OT, NT, TWO>), dim3(nwg), dim3(NT), lds_bytes, st, *a);
+    return (int)hipGetLastError();
+}
 template <typename OT, int NT>
 static int launch_align(const SrAlignArgs *a, int nwg, size_t lds_bytes, hipStream_t st) {
+    if (a->impl == 1)
+        return a->pen.two ? launch_bfs3<OT, NT, true>(a, nwg, lds_bytes, st)
+                          : launch_bfs3<OT, NT, false>(a, nwg, lds_bytes, st);
     return a->pen.two ? launch_align3<OT, NT, true>(a, nwg, lds_bytes, st)
                       : launch_align3<OT, NT, false>(a, nwg, lds_bytes, st);
 }
 
 extern "C" int srk_align(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, int nthreads, void *stream) {
     hipStream_t st = (hipStream_t)stream;
+    if (a->impl == 1 && nthreads >= 512) {
+        if (off16) {
+            if (nthreads == 1024) return a->pen.two ? launch_bfs3<int16_t, 1024, true>(a, nwg, lds_bytes, st) : launch_bfs3<int16_t, 1024, false>(a, nwg, lds_bytes, st);
+            return a->pen.two ? launch_bfs3<int16_t, 512, true>(a, nwg, lds_bytes, st) : launch_bfs3<int16_t, 512, false>(a, nwg, lds_bytes, st);
+        }
+        if (nthreads == 1024) return a->pen.two ? launch_bfs3<int32_t, 1024, true>(a, nwg, lds_bytes, st) : launch_bfs3<int32_t, 1024, false>(a, nwg, lds_bytes, st);
+        return a->pen.two ? launch_bfs3<int32_t, 512, true>(a, nwg, lds_bytes, st) : launch_bfs3<int32_t, 512, false>(a, nwg, lds_bytes, st);
+    }
     if (off16) {
         if (nthreads == 64) return launch_align<int16_t, 64>(a, nwg, lds_bytes, st);
         if (nthreads == 128) return launch_align<int16_t, 128>(a, nwg, lds_bytes, st);

@@ -372,11 +372,14 @@ extern "C" int sr_ctx_load(sr_ctx *c, const sr_seqset *seqs, const sr_params *p)
     c->lds_bytes = (size_t)max_words * 3 * 4;
     if ((long long)c->lds_bytes > (long long)srk_align_max_lds())
         return fail(SR_ERR_UNSUPPORTED, "sequences too long to stage in LDS (limit ~ 200 kb per sequence)");
-    int wg_per_cu = 8;
+    // implementation: 1 = level-synchronous ("bfs") kernel, 0 = one-segment-at-a-time kernel
+    int impl = (std::max(pen.scope, ori.scope) + 1 <= 32) ? 1 : 0;
+    if (const char *e = getenv("SR_ALIGN_IMPL")) impl = atoi(e) ? impl : 0;
+    int wg_per_cu = impl ? 4 : 8;
     if (const char *e = getenv("SR_WG_PER_CU")) wg_per_cu = std::max(1, atoi(e));
-    c->nthreads = 128;
-    if (const char *e = getenv("SR_ALIGN_THREADS")) { int v = atoi(e); if (v == 64 || v == 128 || v == 256) c->nthreads = v; }
-    const size_t lds_per_wg = c->lds_bytes + 8 * 1024;
+    c->nthreads = impl ? 256 : 128;
+    if (const char *e = getenv("SR_ALIGN_THREADS")) { int v = atoi(e); if (v == 64 || v == 128 || v == 256 || (impl && (v == 512 || v == 1024))) c->nthreads = v; }
+    const size_t lds_per_wg = c->lds_bytes + (impl ? 19 : 8) * 1024;
     wg_per_cu = (int)std::min<size_t>((size_t)wg_per_cu, std::max<size_t>(1, (160 * 1024) / lds_per_wg));
     const int ring_scope = std::max(pen.scope, ori.scope);
     const int ring_cap = (int)((2 * maxlen + 3 + 7) & ~7ULL);
@@ -396,7 +399,15 @@ extern "C" int sr_ctx_load(sr_ctx *c, const sr_seqset *seqs, const sr_params *p)
     const uint64_t hist_wg = (uint64_t)hist_levels * 5 * (uint64_t)hist_w + (uint64_t)hist_w;   // + NULL row
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
-    const uint64_t per_wg_bytes = (ring_wg + hist_wg) * osz;
+    // bfs kernel workspace: shared rows (every aligner owns a sub-range) + batched base-case history
+    const int brow = (int)((4 * maxlen + 16 * 64 + 64 + 7) & ~7ULL);
+    const uint64_t bring_wg = ((uint64_t)(ring_scope + 1) + 4ULL * ring_hot + 4ULL * (ring_scope + 1) + 1ULL) * (uint64_t)brow;
+    int bbase_jobs = 16;
+    if (const char *e = getenv("SR_BFS_BASE_JOBS")) bbase_jobs = std::max(1, std::min(16, atoi(e)));
+    const uint64_t bhist_wg = ((uint64_t)hist_levels * 5 + 1) * (uint64_t)bbase_jobs * (uint64_t)hist_w;
+    const uint64_t bseg_wg = 2ULL * SR_BFS_MAXSEG * SR_BFS_SEGREC * 4;          // bytes
+    const uint64_t bbt_wg = (uint64_t)bbase_jobs * SR_BFS_BTCAP * 4;           // bytes
+    const uint64_t per_wg_bytes = impl ? (bring_wg + bhist_wg) * osz + bseg_wg + bbt_wg : (ring_wg + hist_wg) * osz;
     uint64_t budget = (uint64_t)(free_b * 0.6);
     int nwg = cus * wg_per_cu;
     if ((uint64_t)nwg > np) nwg = (int)np;
@@ -428,8 +439,15 @@ extern "C" int sr_ctx_load(sr_ctx *c, const sr_seqset *seqs, const sr_params *p)
     DEV_UPLOAD(c->d_max_score, int32_t, max_score.empty() ? std::vector<int32_t>(1, INT_MAX) : max_score);
     HIPCHK(hipStreamSynchronize(c->stream));   // host vectors go out of scope
     if ((r = dev_alloc(c, &d, sizeof(uint32_t)))) return r; c->d_queue = (uint32_t *)d;
-    if ((r = dev_alloc(c, &d, (uint64_t)nwg * ring_wg * osz))) return r; a.ring = d;
-    if ((r = dev_alloc(c, &d, (uint64_t)nwg * hist_wg * osz))) return r; a.hist = d;
+    if (impl) {
+        if ((r = dev_alloc(c, &d, (uint64_t)nwg * bring_wg * osz))) return r; a.bring = d;
+        if ((r = dev_alloc(c, &d, (uint64_t)nwg * bhist_wg * osz))) return r; a.bhist = d;
+        if ((r = dev_alloc(c, &d, (uint64_t)nwg * bseg_wg))) return r; a.bseg = (int *)d;
+        if ((r = dev_alloc(c, &d, (uint64_t)nwg * bbt_wg))) return r; a.bbt = (uint32_t *)d;
+    } else {
+        if ((r = dev_alloc(c, &d, (uint64_t)nwg * ring_wg * osz))) return r; a.ring = d;
+        if ((r = dev_alloc(c, &d, (uint64_t)nwg * hist_wg * osz))) return r; a.hist = d;
+    }
     if ((r = dev_alloc(c, &d, (size_t)np + 1))) return r; a.is_reverse = (uint8_t *)d;
     if ((r = dev_alloc(c, &d, ((size_t)np + 1) * 4))) return r; a.score = (int32_t *)d;
     if ((r = dev_alloc(c, &d, ((size_t)np + 1) * 4))) return r; a.ori_fwd = (int32_t *)d;
@@ -450,6 +468,7 @@ extern "C" int sr_ctx_load(sr_ctx *c, const sr_seqset *seqs, const sr_params *p)
     a.queue_head = c->d_queue; a.pen = pen; a.ori = ori; a.mem_mode = p->memory_mode;
     a.ring_wg_stride = ring_wg; a.ring_dir_stride = ring_dir; a.ring_cap = ring_cap; a.ring_scope = ring_scope; a.ring_hot = ring_hot;
     a.hist_wg_stride = hist_wg; a.hist_w = hist_w; a.hist_levels = hist_levels;
+    a.impl = impl; a.bring_wg_stride = bring_wg; a.brow = brow; a.bhist_wg_stride = bhist_wg; a.bbase_jobs = bbase_jobs;
     a.cigar_base = d_cbase; a.counters = c->d_counters; a.error_flag = c->d_error;
     SrUniteArgs &u = c->ua;
     memset(&u, 0, sizeof(u));

@@ -8,6 +8,10 @@
 #define SR_MAX_SCOPE 127             // max ring depth supported on device
 #define SR_STACK_DEPTH 64
 #define SR_WG 256                    // threads per workgroup (4 waves of 64)
+#define SR_BFS_MAXSEG 4096            // segments per pair in the bfs kernel's ordered list
+#define SR_BFS_SEGREC 16             // ints per segment record
+#define SR_BFS_MAXACT 32             // segments searched concurrently (2 aligners each)
+#define SR_BFS_BTCAP 1024
 
 enum { SR_C_M = 0, SR_C_I1 = 1, SR_C_I2 = 2, SR_C_D1 = 3, SR_C_D2 = 4 };
 // raw WFA2 op codes used in device CIGAR ops: (len << 4) | op
@@ -55,6 +59,17 @@ struct SrAlignArgs {
     void *hist;                // [nwg][hist_levels][5][hist_w]
     uint64_t hist_wg_stride;
     int hist_w, hist_levels;
+    // level-synchronous ("bfs") kernel workspace, per workgroup
+    int impl;                  // 0 = one segment at a time (sr_align_kernel), 1 = sr_align_bfs_kernel
+    void *bring;               // rows of brow offsets: M[(ring_scope+1)] | hot I1 I2 D1 D2 [ring_hot] each |
+                               //   cold [(ring_scope+1)][4] | NULL row ; every aligner owns a sub-range of each row
+    uint64_t bring_wg_stride;
+    int brow;
+    void *bhist;               // [hist_levels][5][bbase_jobs * hist_w] + NULL row
+    uint64_t bhist_wg_stride;
+    int bbase_jobs;
+    int *bseg;                 // 2 segment lists of SR_BFS_MAXSEG records x SR_BFS_SEGREC ints
+    uint32_t *bbt;             // [bbase_jobs][SR_BFS_BTCAP] reversed run-length ops of finished base cases
     // outputs
     uint8_t *is_reverse;       // [npairs]
     int32_t *score;            // [npairs]

@@ -296,3 +296,14 @@ def test_run_seqrush_cli_end_to_end(gpu, tmp_path, capsys):
     empty = tmp_path / "e.fa"
     empty.write_bytes(b">a\nACGT\n>b\n\n")
     assert main(["-s", str(empty), "-o", str(out), "--no-sort", "--no-compact"]) == 1
+
+
+@pytest.mark.parametrize("impl,threads", [("0", "128"), ("0", "256"), ("1", "128"), ("1", "512")])
+def test_both_align_kernels_and_workgroup_sizes(gpu, impl, threads, monkeypatch):
+    """sr_align_kernel (one segment at a time, SR_ALIGN_IMPL=0) and sr_align_bfs_kernel (level-synchronous,
+    default) implement the same rules: both must match the oracle bit for bit, at every workgroup size"""
+    monkeypatch.setenv("SR_ALIGN_IMPL", impl)
+    monkeypatch.setenv("SR_ALIGN_THREADS", threads)
+    check_parity(synth.indel_family(4, 1500, 0.04, 0.015, 131))
+    check_parity(synth.snp_family(4, 900, 0.06, 132, rc_every=2))
+    check_parity([("p", b"ATCGATCG"), ("t", b"ATCGATCGATCG")], scores="0,5,8,2")
