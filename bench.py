@@ -72,10 +72,17 @@ def main():
         ge.build()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: seqrush_amd has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # SR_BENCH_SINGLE_DEVICE=1 (testing only): all ranks share GPU 0 and talk over gloo, so the
+    # sharded path can be exercised end to end on a one-GPU box
+    single_dev = os.environ.get("SR_BENCH_SINGLE_DEVICE") == "1"
+    dev = 0 if single_dev else local_rank
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if single_dev:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
         dist.barrier()
 
     from seqrush_amd import synth
@@ -84,9 +91,9 @@ def main():
     recs = synth.config_c2(args.nseq)
     ss = SeqSet(recs)
     prm = Params()
-    prm.c.device = local_rank
+    prm.c.device = dev
     prm.c.shard_rank, prm.c.shard_count = rank, world
-    ctx = Context(local_rank)
+    ctx = Context(dev)
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
     ctx.load(ss, prm)                      # pack + upload: inputs resident before timing
@@ -102,7 +109,12 @@ def main():
         ctx.unite()
         if world > 1:
             ctx.labels_device(lab.data_ptr())
-            dist.all_gather_into_tensor(gathered, lab)
+            if single_dev:
+                parts = [torch.empty(ufn, dtype=torch.int64) for _ in range(world)]
+                dist.all_gather(parts, lab.cpu())
+                gathered.copy_(torch.cat(parts))
+            else:
+                dist.all_gather_into_tensor(gathered, lab)
             ctx.merge_labels(gathered.data_ptr(), world)
 
     def fence():
@@ -132,8 +144,12 @@ def main():
         align_ms.append(ctx.kernel_ms(0))
         unite_ms.append(ctx.kernel_ms(1))
     cnt = ctx.counters()
+    labels_sha = None
+    if os.environ.get("SR_BENCH_LABEL_SHA") == "1":
+        import hashlib
+        labels_sha = hashlib.sha256(ctx.download_labels().tobytes()).hexdigest()
     if world > 1:
-        tdt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tdt = torch.tensor([dt], dtype=torch.float64, device="cpu" if single_dev else "cuda")
         dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
         dt = float(tdt.item())
     ms_per_step = dt / args.steps * 1e3
@@ -170,6 +186,8 @@ def main():
                          "wf_cells_per_s": cells / (a_ms * 1e-3)},
             "kernels": cnt,
         }
+        if labels_sha:
+            out["labels_sha256"] = labels_sha
         if world == 1 and not args.no_cpu_baseline:
             ncore = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
             sample = args.cpu_sample_pairs or max(256, 8 * ncore)

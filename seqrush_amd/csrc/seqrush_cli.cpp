@@ -1,0 +1,117 @@
+// seqrush_cli.cpp -- C++ host side above the C ABI: the reference's CLI surface for the hot path
+// (src/main.rs:4-7, Args src/seqrush.rs:17-152, run_seqrush :1839-1853, load_sequences :1801-1837).
+// Everything that computes goes through include/seqrush_amd.h; only --no-sort --no-compact output
+// exists (compaction and the Ygs sort are outside the hot path).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+#include "../../include/seqrush_amd.h"
+
+struct Seq { std::string id; std::string data; };
+
+static bool is_ws(unsigned char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == 0x0b || c == 0x0c; }
+
+// load_sequences, src/seqrush.rs:1801-1837
+static bool load_sequences(const std::string &path, std::vector<Seq> &out) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    std::string line, cur_id, cur;
+    while (std::getline(f, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (!line.empty() && line[0] == '>') {
+            if (!cur_id.empty()) { out.push_back({cur_id, cur}); cur.clear(); }   // data kept when the id was empty (:1812-1820)
+            size_t a = 1;
+            while (a < line.size() && is_ws((unsigned char)line[a])) a++;
+            size_t b = a;
+            while (b < line.size() && !is_ws((unsigned char)line[b])) b++;
+            cur_id = line.substr(a, b - a);
+        } else {
+            size_t a = 0, b = line.size();
+            while (a < b && is_ws((unsigned char)line[a])) a++;
+            while (b > a && is_ws((unsigned char)line[b - 1])) b--;
+            cur.append(line, a, b - a);
+        }
+    }
+    if (!cur_id.empty()) out.push_back({cur_id, cur});
+    return true;
+}
+
+static void usage() {
+    fprintf(stderr, "usage: seqrush_mi355x -s in.fa [-o output.gfa] [-k 0] [-S 0,5,8,2,24,1] [--orientation-scores 0,1,1,1]\n"
+                    "       [-d max_divergence] [-x none|random:F] [--output-alignments out.paf] --no-sort --no-compact [--device N]\n");
+}
+
+int main(int argc, char **argv) {
+    std::string sequences, output = "output.gfa", scores = "0,5,8,2,24,1", ori = "0,1,1,1", sparsify = "none", paf_out, paf_in,
+                aligner = "allwave";
+    long long k = 0;
+    double max_div = -1.0;
+    int device = 0;
+    bool no_sort = false, no_compact = false;
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        auto val = [&](const char *name) -> const char * {
+            if (i + 1 >= argc) { fprintf(stderr, "error: %s needs a value\n", name); exit(2); }
+            return argv[++i];
+        };
+        if (a == "-s" || a == "--sequences") sequences = val("-s");
+        else if (a == "-o" || a == "--output") output = val("-o");
+        else if (a == "-k" || a == "--min-match-length") k = atoll(val("-k"));
+        else if (a == "-t" || a == "--threads") (void)val("-t");               // host threads: unused by the device path
+        else if (a == "-S" || a == "--scores") scores = val("-S");
+        else if (a == "--orientation-scores") ori = val("--orientation-scores");
+        else if (a == "-d" || a == "--max-divergence") max_div = atof(val("-d"));
+        else if (a == "-x" || a == "--sparsify") sparsify = val("-x");
+        else if (a == "-p" || a == "--paf") paf_in = val("-p");
+        else if (a == "--output-alignments") paf_out = val("--output-alignments");
+        else if (a == "--aligner") aligner = val("--aligner");
+        else if (a == "--no-sort") no_sort = true;
+        else if (a == "--no-compact") no_compact = true;
+        else if (a == "--device") device = atoi(val("--device"));
+        else if (a == "-v" || a == "--verbose") {}
+        else { usage(); return 2; }
+    }
+    if (sequences.empty()) { usage(); return 2; }
+    if (!paf_in.empty()) { fprintf(stderr, "Error: -p/--paf input is not implemented (next row of the scope table)\n"); return 1; }
+    if (aligner != "allwave" && aligner != "AllWave") { fprintf(stderr, "Error: aligner '%s' is out of scope; only 'allwave'\n", aligner.c_str()); return 1; }
+    if (!(no_sort && no_compact)) { fprintf(stderr, "Error: only --no-sort --no-compact output is implemented\n"); return 1; }
+    std::vector<Seq> seqs;
+    if (!load_sequences(sequences, seqs)) { fprintf(stderr, "Error: cannot read %s\n", sequences.c_str()); return 1; }
+    printf("Loaded %zu sequences\n", seqs.size());
+    std::string bases;
+    std::vector<uint64_t> offsets(1, 0);
+    std::vector<const char *> names;
+    for (auto &s : seqs) { bases += s.data; offsets.push_back(bases.size()); names.push_back(s.id.c_str()); }
+    sr_seqset set{(uint32_t)seqs.size(), (const uint8_t *)bases.data(), offsets.data(), names.data()};
+    sr_params p;
+    sr_default_params(&p);
+    if (sr_parse_scores(scores.c_str(), &p) || sr_parse_orientation_scores(ori.c_str(), &p) ||
+        sr_parse_sparsification(sparsify.c_str(), &p)) {
+        fprintf(stderr, "Error: %s\n", sr_last_error());
+        return 1;
+    }
+    p.min_match_len = (uint64_t)k; p.max_divergence = max_div; p.device = device; p.canonical_labels = 1;
+    printf("Building graph with %zu sequences (total length: %zu)\n", seqs.size(), bases.size());
+    printf("Total sequence pairs: %zu (sparsification: %s)\n", seqs.size() * seqs.size(), sparsify.c_str());
+    if (!paf_out.empty()) {
+        sr_alignments *al = nullptr;
+        if (sr_align_all(&set, &p, &al)) { fprintf(stderr, "Error: %s\n", sr_last_error()); return 1; }
+        printf("Writing alignments to %s\n", paf_out.c_str());
+        if (sr_write_paf(al, &set, paf_out.c_str())) { fprintf(stderr, "Error: %s\n", sr_last_error()); return 1; }
+        sr_alignments_free(al);
+    }
+    std::vector<uint64_t> labels(2 * bases.size() + 2);
+    if (sr_align_and_unite(&set, &p, labels.data())) { fprintf(stderr, "Error: %s\n", sr_last_error()); return 1; }
+    char *gfa = nullptr;
+    uint64_t nn = 0, ne = 0;
+    if (sr_build_gfa(&set, labels.data(), &gfa, &nn, &ne)) { fprintf(stderr, "Error: %s\n", sr_last_error()); return 1; }
+    std::ofstream o(output, std::ios::binary);
+    o << gfa;
+    sr_free(gfa);
+    printf("Graph written to %s\n", output.c_str());
+    return 0;
+}

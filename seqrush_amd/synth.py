@@ -101,3 +101,38 @@ def config_c1():
 def config_c2(n: int = 64):
     """BASELINE.json configs[1]: 64 synthetic 5 kb sequences (5% SNP), seed 2001"""
     return snp_family(n, 5000, 0.05, 2001)
+
+
+def invert_segment(s: bytes, start: int, length: int) -> bytes:
+    """reverse-complement s[start:start+length] in place (config C5's inversions)"""
+    return s[:start] + reverse_complement(s[start:start + length]) + s[start + length:]
+
+
+def insert_segment(s: bytes, pos: int, length: int, seed: int) -> bytes:
+    return s[:pos] + to_bytes(base_sequence(length, seed)) + s[pos:]
+
+
+def config_c3_like(n: int = 4, L: int = 3000, seed: int = 3001):
+    """scaled surrogate of BASELINE.json configs[2] (HLA-zoo DRB1 is not in the container): 3 %
+    substitutions, 0.3 % short indels and two larger insertions per sequence"""
+    fam = indel_family(n, L, 0.03, 0.003, seed, max_indel=6)
+    out = []
+    for i, (name, s) in enumerate(fam):
+        s = insert_segment(s, (i * 397) % max(1, len(s) - 1), 200 + 50 * i, seed + 100 + i)
+        s = insert_segment(s, (i * 911 + 1500) % max(1, len(s) - 1), 300 + 40 * i, seed + 200 + i)
+        out.append((name, s))
+    return out
+
+
+def config_c5_like(n: int = 4, L: int = 6000, seed: int = 5001):
+    """scaled version of BASELINE.json configs[4]: 2 % substitutions, 0.1 % indels, inverted segments
+    in some sequences and one sequence entirely reverse-complemented"""
+    fam = indel_family(n, L, 0.02, 0.001, seed, max_indel=4)
+    out = []
+    for i, (name, s) in enumerate(fam):
+        if i % 2 == 1:
+            s = invert_segment(s, len(s) // 3, 400 + 100 * i)
+        if i == n - 1:
+            s = reverse_complement(s)
+        out.append((name, s))
+    return out

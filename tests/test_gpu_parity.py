@@ -307,3 +307,78 @@ def test_both_align_kernels_and_workgroup_sizes(gpu, impl, threads, monkeypatch)
     check_parity(synth.indel_family(4, 1500, 0.04, 0.015, 131))
     check_parity(synth.snp_family(4, 900, 0.06, 132, rc_every=2))
     check_parity([("p", b"ATCGATCG"), ("t", b"ATCGATCGATCG")], scores="0,5,8,2")
+
+
+@pytest.mark.parametrize("name,recs,kw", [
+    ("c3-like-drb1-surrogate", synth.config_c3_like(4, 3000), {}),
+    ("c5-like-inversions", synth.config_c5_like(4, 6000), {}),
+    ("c4-like-sparsified", synth.snp_family(12, 600, 0.04, 4001), {"sparsification": "random:0.3"}),
+], ids=lambda x: x if isinstance(x, str) else None)
+def test_scaled_baseline_configs(gpu, name, recs, kw):
+    """scaled-down versions of BASELINE.json configs[2..4] (sizes the oracle finishes in seconds)"""
+    if "sparsification" in kw:
+        # sparsified pair list: compare per-pair results and the partition over exactly the product's pair list
+        ss = SeqSet(recs)
+        p = Params(**kw)
+        from seqrush_amd.seqrush import pair_list
+        pairs = pair_list(len(recs), p)
+        ctx = Context(0); ctx.load(ss, p); ctx.align(); ctx.unite(); ctx.sync()
+        al = ctx.alignments(); labels = ctx.download_labels(); ctx.close()
+        assert [(int(al.query_idx[i]), int(al.target_idx[i])) for i in range(al.n)] == pairs
+        o = ob.OracleSeqRush(records=recs)
+        op = ob.default_params()
+        for i, (q, t) in enumerate(pairs):
+            oa = o.align_pair(op, q, t)
+            assert al.raw_cigar_bytes(i) == oa["cigar"]
+            assert o.process_alignment(ob.cigar_bytes_to_string(oa["cigar"]), q, t, 0, oa["is_reverse"]) >= 0
+        assert np.array_equal(o.canonical_labels(), labels)
+        assert len(pairs) < len(recs) ** 2
+    else:
+        al, labels, cnt = check_parity(recs, **kw)
+        if name.startswith("c5"):
+            assert al.is_reverse.any()
+
+
+def test_cpp_cli_binary(gpu, tmp_path):
+    """C++ host (seqrush_amd/csrc/seqrush_cli.cpp) above the C ABI: same GFA as the oracle"""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "seqrush_amd", "seqrush_mi355x")
+    assert os.path.exists(exe), "build() must produce the C++ CLI"
+    recs = synth.snp_family(5, 400, 0.05, 141, rc_every=5)
+    fa = tmp_path / "in.fa"
+    fa.write_bytes(b"".join(b">" + n.encode() + b"\n" + s + b"\n" for n, s in recs))
+    out = tmp_path / "o.gfa"
+    r = subprocess.run([exe, "-s", str(fa), "-o", str(out), "-k", "0", "--no-sort", "--no-compact"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "Loaded 5 sequences" in r.stdout and f"Graph written to {out}" in r.stdout
+    o = ob.OracleSeqRush(records=recs)
+    o.align_and_unite(ob.default_params())
+    assert canon_gfa(out.read_text()) == canon_gfa(o.gfa(canonical=True)[0])
+    r = subprocess.run([exe, "-s", str(fa), "-o", str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "only --no-sort --no-compact" in r.stderr
+
+
+def test_multi_rank_bench_matches_single_rank(gpu):
+    """bench.py's sharded path (pair shard -> per-rank forest -> label all-gather -> replay merge) with 2
+    ranks sharing this GPU over gloo gives the same merged partition as 1 rank"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SR_BENCH_LABEL_SHA="1")
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--nseq", "8", "--steps", "1", "--warmup", "0",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads(one.stdout.strip().split("\n")[-1])
+    env["SR_BENCH_SINGLE_DEVICE"] = "1"
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--nseq", "8", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert two.returncode == 0, two.stderr[-2000:]
+    d2 = json.loads(two.stdout.strip().split("\n")[-1])
+    assert d2["n_gpus"] == 2 and d2["config"]["pairs_per_gpu"] == 32
+    assert d1["labels_sha256"] == d2["labels_sha256"]
+    for d in (d1, d2):
+        assert d["metric"].startswith("aligned pairs/sec") and d["unit"] == "pairs/s" and "roofline" in d
