@@ -160,6 +160,9 @@ def main():
         cells = cnt["wf_cells"]
         alg_bytes = cells * BYTES_PER_CELL_2P + ctx.num_pairs * (2 * 1250 * 2 + 8 * 1024)
         achieved = alg_bytes / (a_ms * 1e-3) / 1e9
+        # SR_ALIGN_IMPL=0 selects the older per-WG pair kernel; default is the level-synchronous one
+        align_kernel_name = ("sr_align_kernel" if os.environ.get("SR_ALIGN_IMPL") == "0"
+                             else "sr_align_bfs_kernel")
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
         if world == 1 and os.path.exists(tpath):
@@ -179,7 +182,7 @@ def main():
                                    f"incl. self = {total_pairs} ordered pairs, -k 0 -S 0,5,8,2,24,1 "
                                    f"--orientation-scores 0,1,1,1, biWFA (Ultralow)",
                        "pairs_per_gpu": ctx.num_pairs, "parallelism": f"pair-shard x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "sr_align_kernel", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": align_kernel_name, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel_ms": a_ms, "wf_cells_per_launch": cells,
                          "bytes_per_cell": BYTES_PER_CELL_2P, "unite_kernel_ms": u_ms,
