@@ -401,7 +401,7 @@ extern "C" int sr_ctx_load(sr_ctx *c, const sr_seqset *seqs, const sr_params *p)
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
     // bfs kernel workspace: shared rows (every aligner owns a sub-range) + batched base-case history
     const int brow = (int)((4 * maxlen + 16 * 64 + 64 + 7) & ~7ULL);
-    const uint64_t bring_wg = ((uint64_t)(ring_scope + 1) + 4ULL * ring_hot + 4ULL * (ring_scope + 1) + 1ULL) * (uint64_t)brow;
+    const uint64_t bring_wg = ((uint64_t)(ring_scope + 1) + 4ULL * ring_hot + 4ULL * (ring_scope + 1) + 2ULL) * (uint64_t)brow;   // + NULL row + U row
     int bbase_jobs = 16;
     if (const char *e = getenv("SR_BFS_BASE_JOBS")) bbase_jobs = std::max(1, std::min(16, atoi(e)));
     const uint64_t bhist_wg = ((uint64_t)hist_levels * 5 + 1) * (uint64_t)bbase_jobs * (uint64_t)hist_w;

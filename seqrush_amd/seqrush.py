@@ -297,8 +297,9 @@ class Context:
         return dict(wf_cells=int(out[0]), wf_steps=int(out[1]), base_segments=int(out[2]),
                     breakpoint_searches=int(out[3]), united_bases=int(out[4]), match_runs=int(out[5]),
                     ticks_orientation=int(out[6]), ticks_breakpoint=int(out[7]), ticks_base=int(out[8]),
-                    ticks_breakpoint_top=int(out[9]), ticks_pair=int(out[10]), tk_setup=int(out[11]),
-                    tk_cells=int(out[12]), tk_reduce=int(out[13]), tk_bp_barrier=int(out[14]))
+                    bp_passes=int(out[9]), ticks_pair=int(out[10]), tk_pass=int(out[11]),
+                    tk_barrier=int(out[12]), tk_control=int(out[13]), tk_phase2=int(out[14]),
+                    tk_tail=int(out[15]))
 
     def close(self):
         if self._h:
