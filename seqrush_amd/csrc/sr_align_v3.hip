@@ -17,16 +17,9 @@
 // oracle/wfa.c (restated WFA2-lib semantics); reference call sites:
 // src/seqrush.rs:611-757, 1134-1481; src/bidirected_union_find.rs:60-98;
 // uf_rush-0.2.1/src/lib.rs:112-208.  Integer DP and atomics only: no MFMA.
-#include <hip/hip_runtime.h>
-#include <limits.h>
-#include "sr_internal.h"
+#include "sr_dev_common.h"
 
-#define WG SR_WG   // unite kernel workgroup size
-#define NULLV SR_NULL_OFF
 #define BT_TMP_CAP 1024
-#ifndef SR_MIN_WAVES
-#define SR_MIN_WAVES 4
-#endif
 
 struct Seg { int pb, pe, tb, te; int cb, ce; int score_rem; };
 
@@ -63,19 +56,6 @@ struct Shared {
 };
 
 __shared__ Shared g_sh;
-extern __shared__ uint32_t lds_seq[];     // 3 regions of max_words: P fwd, P rc, T
-
-#define RFL(x) __builtin_amdgcn_readfirstlane(x)
-__device__ __forceinline__ unsigned long long rfl64(unsigned long long v) {
-    const unsigned lo = RFL((unsigned)v), hi = RFL((unsigned)(v >> 32));
-    return ((unsigned long long)hi << 32) | lo;
-}
-
-// Explicit address spaces: pointers that travel inside a by-value kernel
-// argument struct are generic ("flat") for hipcc; flat loads cost a VGPR pair
-// per address and the slow path.  GP = global (HBM) pointer, LP = LDS pointer.
-template <typename T> using GP = T __attribute__((address_space(1))) *;
-typedef const uint32_t __attribute__((address_space(3))) *LP;
 
 // Register copy of a DirL.  Modular (score-only) mode: M ring of scope+1
 // levels, "hot" I/D rings of e+2 levels (all the recurrences read), plus a
@@ -163,64 +143,6 @@ __device__ __forceinline__ GP<OT> hrowk(const Dir<OT> &d, int s, int comp) {
     return d.cold + ((size_t)(s % d.nsc) * 4 + (comp - 1)) * (size_t)d.cap + d.shift;
 }
 
-__device__ __forceinline__ int reach(const SrPen &p, int s, int begin) {
-    int r;
-    if (begin == SR_C_M) {
-        r = (s >= p.o1 + p.e1) ? (s - p.o1) / p.e1 : 0;
-        if (p.two && s >= p.o2 + p.e2) r = max(r, (s - p.o2) / p.e2);
-    } else {
-        r = s / p.e1;
-        if (p.two) r = max(r, s / p.e2);
-    }
-    return r;
-}
-
-__device__ __forceinline__ int bnd(int c, unsigned lim) {
-    return ((unsigned)c > lim) ? NULLV : c;
-}
-
-__device__ __forceinline__ int wave_max(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
-    return v;
-}
-
-// 16 bases starting at base i (2 bits each, base i in the low bits)
-__device__ __forceinline__ uint32_t win_fwd(LP w, int i) {
-    const int wi = i >> 4, sh = (i & 15) << 1;
-    const uint64_t v = ((uint64_t)w[wi + 1] << 32) | (uint64_t)w[wi];
-    return (uint32_t)(v >> sh);
-}
-// 16 bases ending at base i (base i in the high bits)
-__device__ __forceinline__ uint32_t win_rev(LP w, int i) {
-    return win_fwd(w, i - 15);
-}
-
-// number of equal bases walking forward from (pi, ti), at most n
-__device__ __forceinline__ int ext_fwd(LP P, LP T, int pi, int ti, int n) {
-    int tot = 0;
-    while (tot < n) {
-        const uint32_t x = win_fwd(P, pi + tot) ^ win_fwd(T, ti + tot);
-        int c = x ? ((__ffs((int)x) - 1) >> 1) : 16;
-        c = min(c, n - tot);
-        tot += c;
-        if (x) break;
-    }
-    return tot;
-}
-// same walking backward from (pi, ti) inclusive
-__device__ __forceinline__ int ext_rev(LP P, LP T, int pi, int ti, int n) {
-    int tot = 0;
-    while (tot < n) {
-        const uint32_t x = win_rev(P, pi - tot) ^ win_rev(T, ti - tot);
-        int c = x ? (__clz((int)x) >> 1) : 16;
-        c = min(c, n - tot);
-        tot += c;
-        if (x) break;
-    }
-    return tot;
-}
-
 // ---- one score step, batched ------------------------------------------------
 // Per-step uniform description of one aligner's rows (all unshifted: indexed
 // by idx = k + shift >= 0).  Source levels that do not exist yet (score < 0)
@@ -257,26 +179,6 @@ __device__ __forceinline__ void step_rows(const Dir<OT> &d, const SrPen &pen, St
         r.cI1 = rowqc(d, SR_C_I1); r.cD1 = rowqc(d, SR_C_D1);
         r.cI2 = rowqc(d, SR_C_I2); r.cD2 = rowqc(d, SR_C_D2);
     }
-}
-
-// Four adjacent diagonals per thread: the 2-byte cells of one ring row are
-// moved with 8-byte (int16) / 16-byte (int32) accesses -- the vector memory
-// pipe is paid per wave instruction, not per byte.
-template <typename OT> using V4 = OT __attribute__((ext_vector_type(4)));
-
-template <typename OT>
-struct GroupIn {
-    V4<OT> mo1, i1, d1, mo2, i2, d2, mx;
-    int mo1L, mo1R, i1L, d1R, mo2L, mo2R, i2L, d2R;
-};
-
-template <typename OT>
-__device__ __forceinline__ V4<OT> ld4(GP<OT> row, unsigned idx0) {
-    return *(const V4<OT> __attribute__((address_space(1))) *)(row + idx0);
-}
-template <typename OT>
-__device__ __forceinline__ void st4(GP<OT> row, unsigned idx0, V4<OT> v) {
-    *(V4<OT> __attribute__((address_space(1))) *)(row + idx0) = v;
 }
 
 // group g covers idx 4g .. 4g+3 (idx = k + shift)
@@ -481,15 +383,6 @@ __device__ __forceinline__ void wf_step_nl(int do_a_, int chk_a_, int do_b_, int
     }
 }
 
-// ---------------------------------------------------------------- CIGAR out
-__device__ __forceinline__ void cig_append(GP<uint32_t> ops, uint32_t &cnt, uint32_t cap, int op,
-                                           int len, int &err) {
-    if (len <= 0) return;
-    if (cnt > 0 && (int)(ops[cnt - 1] & 15u) == op) { ops[cnt - 1] += (uint32_t)len << 4; return; }
-    if (cnt >= cap) { err |= SR_DEV_ERR_CIGAR_OVERFLOW; return; }
-    ops[cnt++] = ((uint32_t)len << 4) | (uint32_t)op;
-}
-
 __device__ __forceinline__ void bt_push(int op, int len, int &err) {
     if (len <= 0) return;
     int n = g_sh.bt_n;
@@ -497,11 +390,6 @@ __device__ __forceinline__ void bt_push(int op, int len, int &err) {
     if (n >= BT_TMP_CAP) { err |= SR_DEV_ERR_CIGAR_OVERFLOW; return; }
     g_sh.bt_tmp[n] = ((uint32_t)len << 4) | (uint32_t)op;
     g_sh.bt_n = n + 1;
-}
-
-__device__ __forceinline__ void bt_best(int &bo, int &bty, int off, int type) {
-    if (off < 0) return;
-    if (off > bo || (off == bo && type > bty)) { bo = off; bty = type; }
 }
 
 // thread-0 backtrace over the full history of aligner dl[0] (oracle/wfa.c
@@ -842,11 +730,6 @@ __device__ __forceinline__ int wfa_score_only(int plen, int tlen, const SrAlignA
     return res;
 }
 
-template <int NT>
-__device__ __forceinline__ void load_seq_lds(uint32_t *dst, GP<const uint32_t> src, int nwords_with_pad) {
-    for (int i = threadIdx.x; i < nwords_with_pad; i += NT) dst[i] = src[i];
-}
-
 template <typename OT, int NT, bool TWO>
 __global__ void __launch_bounds__(NT, SR_MIN_WAVES) sr_align_kernel(SrAlignArgs a) {
     const int tid = threadIdx.x;
@@ -994,200 +877,7 @@ __global__ void __launch_bounds__(NT, SR_MIN_WAVES) sr_align_kernel(SrAlignArgs 
     }
 }
 
-#include "sr_align_bfs.inc"
-
-// ------------------------------------------------------------------ UF
-#define UF_PARENT_MASK 0x03FFFFFFFFFFFFFFULL
-#define UF_RANK_SHIFT 58
-
-__device__ __forceinline__ unsigned long long uf_load(unsigned long long *nodes, unsigned long long i) {
-    return __hip_atomic_load(&nodes[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ bool uf_cas(unsigned long long *nodes, unsigned long long i,
-                                       unsigned long long expect, unsigned long long desired) {
-    return __hip_atomic_compare_exchange_strong(&nodes[i], &expect, desired, __ATOMIC_RELAXED,
-                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// UFRush::find with path halving (uf_rush lib.rs:112-133)
-__device__ __forceinline__ unsigned long long uf_find(unsigned long long *nodes, unsigned long long x,
-                                                      int &err) {
-    unsigned long long x_node = uf_load(nodes, x);
-    int guard = 0;
-    while (x != (x_node & UF_PARENT_MASK)) {
-        const unsigned long long x_parent = x_node & UF_PARENT_MASK;
-        const unsigned long long x_parent_node = uf_load(nodes, x_parent);
-        const unsigned long long x_pp = x_parent_node & UF_PARENT_MASK;
-        const unsigned long long x_new = x_pp | (x_node & ~UF_PARENT_MASK);
-        if (x_new != x_node) (void)uf_cas(nodes, x, x_node, x_new);
-        x = x_pp;
-        x_node = uf_load(nodes, x);
-        if (++guard > (1 << 20)) { err |= SR_DEV_ERR_UF_SPIN; break; }
-    }
-    return x;
-}
-
-// UFRush::unite (uf_rush lib.rs:159-208)
-__device__ __forceinline__ bool uf_unite(unsigned long long *nodes, unsigned long long x,
-                                         unsigned long long y, int &err) {
-    for (int guard = 0; guard < (1 << 16); guard++) {
-        unsigned long long x_rep = uf_find(nodes, x, err);
-        unsigned long long y_rep = uf_find(nodes, y, err);
-        if (x_rep == y_rep) return false;
-        const unsigned long long x_node = uf_load(nodes, x_rep);
-        const unsigned long long y_node = uf_load(nodes, y_rep);
-        unsigned long long x_rank = x_node >> UF_RANK_SHIFT, y_rank = y_node >> UF_RANK_SHIFT;
-        if (x_rank > y_rank || (x_rank == y_rank && x_rep > y_rep)) {
-            unsigned long long tmp = x_rep; x_rep = y_rep; y_rep = tmp;
-            tmp = x_rank; x_rank = y_rank; y_rank = tmp;
-        }
-        const unsigned long long cur = x_rep | (x_rank << UF_RANK_SHIFT);
-        const unsigned long long nw = y_rep | (x_rank << UF_RANK_SHIFT);
-        if (uf_cas(nodes, x_rep, cur, nw)) {
-            if (x_rank == y_rank) {
-                const unsigned long long cv = y_rep | (y_rank << UF_RANK_SHIFT);
-                const unsigned long long nv = y_rep | ((y_rank + 1) << UF_RANK_SHIFT);
-                (void)uf_cas(nodes, y_rep, cv, nv);
-            }
-            return true;
-        }
-    }
-    err |= SR_DEV_ERR_UF_SPIN;
-    return false;
-}
-
-// SeqRush::new state (seqrush.rs:324-328): N sequential unite(2i, 2i+1) on a
-// fresh forest always ends with parent[2i] = 2i+1 (rank 0) and 2i+1 a root
-// of rank 1 (uf_rush tie rule: larger index wins).
-__global__ void sr_uf_init_kernel(unsigned long long *nodes, unsigned long long total_len,
-                                  unsigned long long uf_size) {
-    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < uf_size;
-         i += stride) {
-        unsigned long long v;
-        if ((i >> 1) < total_len) v = (i & 1) ? (i | (1ULL << UF_RANK_SHIFT)) : (i + 1);
-        else v = i;
-        nodes[i] = v;
-    }
-}
-
-// process_alignment + unite_matching_region, one pair per workgroup
-__global__ void __launch_bounds__(WG) sr_unite_kernel(SrUniteArgs a) {
-    __shared__ unsigned sq[WG], st[WG], sm[WG];   // inclusive scans of one chunk
-    __shared__ unsigned long long carry_q, carry_t;
-    __shared__ unsigned wsum[3][WG / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    unsigned long long united = 0, runs = 0;
-    int err = 0;
-    for (uint32_t pair = blockIdx.x; pair < a.npairs; pair += gridDim.x) {
-        const uint32_t cnt = a.cigar_cnt[pair];
-        if (a.score[pair] < 0 || a.score[pair] > a.max_score[pair]) continue;   // uniform
-        const uint32_t q = a.pair_q[pair], t = a.pair_t[pair];
-        const unsigned long long qoff = a.seq_goff[q], toff = a.seq_goff[t];
-        const unsigned long long qlen = a.seqlen[q];
-        const bool rc = a.is_reverse[pair] != 0;
-        const uint32_t *ops = a.cigar_ops + a.cigar_base[pair];
-        if (tid == 0) { carry_q = 0; carry_t = 0; }
-        __syncthreads();
-        for (uint32_t base = 0; base < cnt; base += WG) {
-            const uint32_t i = base + tid;
-            unsigned dq = 0, dt = 0, ml = 0;
-            if (i < cnt) {
-                const uint32_t op = ops[i] & 15u; const unsigned len = ops[i] >> 4;
-                if (op == SR_OP_M) { dq = len; dt = len; if ((unsigned long long)len >= a.min_match_len) ml = len; }
-                else if (op == SR_OP_X) { dq = len; dt = len; }
-                else if (op == SR_OP_I) dt = len;       // raw 'I' consumes text (target)
-                else dq = len;                           // raw 'D' consumes pattern (query)
-            }
-            // block inclusive scan of (dq, dt, ml)
-            unsigned vq = dq, vt = dt, vm = ml;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const unsigned nq = __shfl_up(vq, o, 64), nt = __shfl_up(vt, o, 64), nm = __shfl_up(vm, o, 64);
-                if (lane >= o) { vq += nq; vt += nt; vm += nm; }
-            }
-            if (lane == 63) { wsum[0][wv] = vq; wsum[1][wv] = vt; wsum[2][wv] = vm; }
-            __syncthreads();
-            unsigned aq = 0, at = 0, am = 0;
-            for (int w = 0; w < wv; w++) { aq += wsum[0][w]; at += wsum[1][w]; am += wsum[2][w]; }
-            vq += aq; vt += at; vm += am;
-            sq[tid] = vq; st[tid] = vt; sm[tid] = vm;
-            __syncthreads();
-            const unsigned total_m = sm[WG - 1];
-            const unsigned long long cq = carry_q, ct = carry_t;
-            if (ml) runs++;
-            for (unsigned j = tid; j < total_m; j += WG) {
-                // op index: first idx with sm[idx] > j
-                int lo = 0, hi = WG - 1;
-                while (lo < hi) { const int mid = (lo + hi) >> 1; if (sm[mid] > j) hi = mid; else lo = mid + 1; }
-                const unsigned len = ops[base + lo] >> 4;
-                const unsigned within = j - (sm[lo] - len);
-                const unsigned long long qpos = cq + (sq[lo] - len) + within;   // query-space index
-                const unsigned long long tpos = ct + (st[lo] - len) + within;
-                unsigned long long p1, p2 = (toff + tpos) << 1;
-                if (rc) p1 = ((qoff + (qlen - 1 - qpos)) << 1) | 1ULL;
-                else p1 = (qoff + qpos) << 1;
-                if (p1 != p2) uf_unite(a.nodes, p1, p2, err);
-                united++;
-            }
-            __syncthreads();
-            if (tid == 0) { carry_q = cq + sq[WG - 1]; carry_t = ct + st[WG - 1]; }
-            __syncthreads();
-        }
-    }
-    // counters
-    for (int o = 32; o > 0; o >>= 1) {
-        united += __shfl_xor(united, o, 64);
-        runs += __shfl_xor(runs, o, 64);
-    }
-    if (lane == 0) {
-        if (united) atomicAdd(&a.counters[4], united);
-        if (runs) atomicAdd(&a.counters[5], runs);
-    }
-    if (err) atomicOr(a.error_flag, err);
-}
-
-// canonical labels: minarr[root] = min element, labels[i] = minarr[find(i)]
-__global__ void sr_minroot_kernel(unsigned long long *nodes, unsigned long long n,
-                                  unsigned long long *minarr, int *error_flag) {
-    int err = 0;
-    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const unsigned long long r = uf_find(nodes, i, err);
-        atomicMin(&minarr[r], i);
-    }
-    if (err) atomicOr(error_flag, err);
-}
-__global__ void sr_fill_kernel(unsigned long long *p, unsigned long long n, unsigned long long v) {
-    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
-}
-__global__ void sr_label_kernel(unsigned long long *nodes, unsigned long long n,
-                                const unsigned long long *minarr, unsigned long long *labels,
-                                int *error_flag) {
-    int err = 0;
-    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const unsigned long long r = uf_find(nodes, i, err);
-        labels[i] = minarr[r];
-    }
-    if (err) atomicOr(error_flag, err);
-}
-// replay-unite of `count` gathered label arrays
-__global__ void sr_merge_kernel(unsigned long long *nodes, unsigned long long n,
-                                const unsigned long long *labels, unsigned count, int *error_flag) {
-    int err = 0;
-    const unsigned long long total = n * (unsigned long long)count;
-    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-    for (unsigned long long j = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += stride) {
-        const unsigned long long i = j % n;
-        const unsigned long long l = labels[j];
-        if (l != i && l < n) uf_unite(nodes, i, l, err);
-    }
-    if (err) atomicOr(error_flag, err);
-}
-
-// ------------------------------------------------------------------ launchers
+// ------------------------------------------------------------------ launcher
 extern "C" int srk_align_max_lds(void) { return 160 * 1024 - (int)sizeof(Shared) - 1024; }
 
 template <typename OT, int NT, bool TWO>
@@ -1200,35 +890,13 @@ static int launch_align3(const SrAlignArgs *a, int nwg, size_t lds_bytes, hipStr
     hipLaunchKernelGGL((sr_align_kernel<OT, NT, TWO>), dim3(nwg), dim3(NT), lds_bytes, st, *a);
     return (int)hipGetLastError();
 }
-template <typename OT, int NT, bool TWO>
-static int launch_bfs3(const SrAlignArgs *a, int nwg, size_t lds_bytes, hipStream_t st) {
-    if (lds_bytes > 32 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)sr_align_bfs_kernel<OT, NT, TWO>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return (int)e;
-    }
-    hipLaunchKernelGGL((sr_align_bfs_kernel<OT, NT, TWO>), dim3(nwg), dim3(NT), lds_bytes, st, *a);
-    return (int)hipGetLastError();
-}
 template <typename OT, int NT>
 static int launch_align(const SrAlignArgs *a, int nwg, size_t lds_bytes, hipStream_t st) {
-    if (a->impl == 1)
-        return a->pen.two ? launch_bfs3<OT, NT, true>(a, nwg, lds_bytes, st)
-                          : launch_bfs3<OT, NT, false>(a, nwg, lds_bytes, st);
     return a->pen.two ? launch_align3<OT, NT, true>(a, nwg, lds_bytes, st)
                       : launch_align3<OT, NT, false>(a, nwg, lds_bytes, st);
 }
-
-extern "C" int srk_align(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, int nthreads, void *stream) {
+extern "C" int srk_align_v3(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, int nthreads, void *stream) {
     hipStream_t st = (hipStream_t)stream;
-    if (a->impl == 1 && nthreads >= 512) {
-        if (off16) {
-            if (nthreads == 1024) return a->pen.two ? launch_bfs3<int16_t, 1024, true>(a, nwg, lds_bytes, st) : launch_bfs3<int16_t, 1024, false>(a, nwg, lds_bytes, st);
-            return a->pen.two ? launch_bfs3<int16_t, 512, true>(a, nwg, lds_bytes, st) : launch_bfs3<int16_t, 512, false>(a, nwg, lds_bytes, st);
-        }
-        if (nthreads == 1024) return a->pen.two ? launch_bfs3<int32_t, 1024, true>(a, nwg, lds_bytes, st) : launch_bfs3<int32_t, 1024, false>(a, nwg, lds_bytes, st);
-        return a->pen.two ? launch_bfs3<int32_t, 512, true>(a, nwg, lds_bytes, st) : launch_bfs3<int32_t, 512, false>(a, nwg, lds_bytes, st);
-    }
     if (off16) {
         if (nthreads == 64) return launch_align<int16_t, 64>(a, nwg, lds_bytes, st);
         if (nthreads == 128) return launch_align<int16_t, 128>(a, nwg, lds_bytes, st);
@@ -1237,38 +905,4 @@ extern "C" int srk_align(const SrAlignArgs *a, int nwg, size_t lds_bytes, int of
     if (nthreads == 64) return launch_align<int32_t, 64>(a, nwg, lds_bytes, st);
     if (nthreads == 128) return launch_align<int32_t, 128>(a, nwg, lds_bytes, st);
     return launch_align<int32_t, 256>(a, nwg, lds_bytes, st);
-}
-
-extern "C" int srk_unite(const SrUniteArgs *a, int nwg, void *stream) {
-    hipLaunchKernelGGL(sr_unite_kernel, dim3(nwg), dim3(WG), 0, (hipStream_t)stream, *a);
-    return (int)hipGetLastError();
-}
-
-extern "C" int srk_uf_init(unsigned long long *nodes, uint64_t total_len, uint64_t uf_size, void *stream) {
-    const int nb = (int)((uf_size + 255) / 256 > 4096 ? 4096 : (uf_size + 255) / 256);
-    hipLaunchKernelGGL(sr_uf_init_kernel, dim3(nb ? nb : 1), dim3(256), 0, (hipStream_t)stream, nodes,
-                       (unsigned long long)total_len, (unsigned long long)uf_size);
-    return (int)hipGetLastError();
-}
-
-extern "C" int srk_labels(unsigned long long *nodes, uint64_t uf_size, unsigned long long *minarr,
-                          unsigned long long *labels, int *error_flag, void *stream) {
-    const int nb = (int)((uf_size + 255) / 256 > 4096 ? 4096 : (uf_size + 255) / 256);
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(sr_fill_kernel, dim3(nb ? nb : 1), dim3(256), 0, st, minarr,
-                       (unsigned long long)uf_size, ~0ULL);
-    hipLaunchKernelGGL(sr_minroot_kernel, dim3(nb ? nb : 1), dim3(256), 0, st, nodes,
-                       (unsigned long long)uf_size, minarr, error_flag);
-    hipLaunchKernelGGL(sr_label_kernel, dim3(nb ? nb : 1), dim3(256), 0, st, nodes,
-                       (unsigned long long)uf_size, minarr, labels, error_flag);
-    return (int)hipGetLastError();
-}
-
-extern "C" int srk_merge(unsigned long long *nodes, uint64_t uf_size, const unsigned long long *labels,
-                         uint32_t count, int *error_flag, void *stream) {
-    const uint64_t total = uf_size * count;
-    const int nb = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-    hipLaunchKernelGGL(sr_merge_kernel, dim3(nb ? nb : 1), dim3(256), 0, (hipStream_t)stream, nodes,
-                       (unsigned long long)uf_size, labels, count, error_flag);
-    return (int)hipGetLastError();
 }

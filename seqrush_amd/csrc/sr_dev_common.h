@@ -1,0 +1,122 @@
+// sr_dev_common.h -- device helpers shared by the alignment kernels (gfx950, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include "sr_internal.h"
+
+#define NULLV SR_NULL_OFF
+#ifndef SR_MIN_WAVES
+#define SR_MIN_WAVES 4
+#endif
+
+extern __shared__ uint32_t lds_seq[];     // 3 regions of max_words: P fwd, P rc, T
+
+#define RFL(x) __builtin_amdgcn_readfirstlane(x)
+__device__ __forceinline__ unsigned long long rfl64(unsigned long long v) {
+    const unsigned lo = RFL((unsigned)v), hi = RFL((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// Explicit address spaces: pointers that travel inside a by-value kernel
+// argument struct are generic ("flat") for hipcc; flat loads cost a VGPR pair
+// per address and the slow path.  GP = global (HBM) pointer, LP = LDS pointer.
+template <typename T> using GP = T __attribute__((address_space(1))) *;
+typedef const uint32_t __attribute__((address_space(3))) *LP;
+
+__device__ __forceinline__ int reach(const SrPen &p, int s, int begin) {
+    int r;
+    if (begin == SR_C_M) {
+        r = (s >= p.o1 + p.e1) ? (s - p.o1) / p.e1 : 0;
+        if (p.two && s >= p.o2 + p.e2) r = max(r, (s - p.o2) / p.e2);
+    } else {
+        r = s / p.e1;
+        if (p.two) r = max(r, s / p.e2);
+    }
+    return r;
+}
+
+__device__ __forceinline__ int bnd(int c, unsigned lim) {
+    return ((unsigned)c > lim) ? NULLV : c;
+}
+
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// 16 bases starting at base i (2 bits each, base i in the low bits)
+__device__ __forceinline__ uint32_t win_fwd(LP w, int i) {
+    const int wi = i >> 4, sh = (i & 15) << 1;
+    const uint64_t v = ((uint64_t)w[wi + 1] << 32) | (uint64_t)w[wi];
+    return (uint32_t)(v >> sh);
+}
+// 16 bases ending at base i (base i in the high bits)
+__device__ __forceinline__ uint32_t win_rev(LP w, int i) {
+    return win_fwd(w, i - 15);
+}
+
+// number of equal bases walking forward from (pi, ti), at most n
+__device__ __forceinline__ int ext_fwd(LP P, LP T, int pi, int ti, int n) {
+    int tot = 0;
+    while (tot < n) {
+        const uint32_t x = win_fwd(P, pi + tot) ^ win_fwd(T, ti + tot);
+        int c = x ? ((__ffs((int)x) - 1) >> 1) : 16;
+        c = min(c, n - tot);
+        tot += c;
+        if (x) break;
+    }
+    return tot;
+}
+// same walking backward from (pi, ti) inclusive
+__device__ __forceinline__ int ext_rev(LP P, LP T, int pi, int ti, int n) {
+    int tot = 0;
+    while (tot < n) {
+        const uint32_t x = win_rev(P, pi - tot) ^ win_rev(T, ti - tot);
+        int c = x ? (__clz((int)x) >> 1) : 16;
+        c = min(c, n - tot);
+        tot += c;
+        if (x) break;
+    }
+    return tot;
+}
+
+// Four adjacent diagonals per thread: the 2-byte cells of one ring row are
+// moved with 8-byte (int16) / 16-byte (int32) accesses -- the vector memory
+// pipe is paid per wave instruction, not per byte.
+template <typename OT> using V4 = OT __attribute__((ext_vector_type(4)));
+
+template <typename OT>
+struct GroupIn {
+    V4<OT> mo1, i1, d1, mo2, i2, d2, mx;
+    int mo1L, mo1R, i1L, d1R, mo2L, mo2R, i2L, d2R;
+};
+
+template <typename OT>
+__device__ __forceinline__ V4<OT> ld4(GP<OT> row, unsigned idx0) {
+    return *(const V4<OT> __attribute__((address_space(1))) *)(row + idx0);
+}
+template <typename OT>
+__device__ __forceinline__ void st4(GP<OT> row, unsigned idx0, V4<OT> v) {
+    *(V4<OT> __attribute__((address_space(1))) *)(row + idx0) = v;
+}
+
+// ---------------------------------------------------------------- CIGAR out
+__device__ __forceinline__ void cig_append(GP<uint32_t> ops, uint32_t &cnt, uint32_t cap, int op,
+                                           int len, int &err) {
+    if (len <= 0) return;
+    if (cnt > 0 && (int)(ops[cnt - 1] & 15u) == op) { ops[cnt - 1] += (uint32_t)len << 4; return; }
+    if (cnt >= cap) { err |= SR_DEV_ERR_CIGAR_OVERFLOW; return; }
+    ops[cnt++] = ((uint32_t)len << 4) | (uint32_t)op;
+}
+
+__device__ __forceinline__ void bt_best(int &bo, int &bty, int off, int type) {
+    if (off < 0) return;
+    if (off > bo || (off == bo && type > bty)) { bo = off; bty = type; }
+}
+
+template <int NT>
+__device__ __forceinline__ void load_seq_lds(uint32_t *dst, GP<const uint32_t> src, int nwords_with_pad) {
+    for (int i = threadIdx.x; i < nwords_with_pad; i += NT) dst[i] = src[i];
+}
+
