@@ -1,0 +1,36 @@
+// sr_align_blk.hip -- translation unit of the score-blocked, wave-tiled biWFA kernel (see sr_align_blk.inc)
+#include "sr_dev_common.h"
+#include "sr_align_bfs.inc"
+#ifndef SR_BLK_MIN_WAVES
+#define SR_BLK_MIN_WAVES 2
+#endif
+#include "sr_align_blk.inc"
+
+template <typename OT, int NT, bool TWO>
+static int launch_blk3(const SrAlignArgs *a, int nwg, size_t lds_bytes, hipStream_t st) {
+    if (lds_bytes > 16 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)sr_align_blk_kernel<OT, NT, TWO, 5, 2, 1>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL((sr_align_blk_kernel<OT, NT, TWO, 5, 2, 1>), dim3(nwg), dim3(NT), lds_bytes, st, *a);
+    return (int)hipGetLastError();
+}
+// penalty sets this build has a blocked instance for (host side asks before choosing impl 2)
+extern "C" int srk_align_blk_supports(const SrPen *pen, const SrPen *ori) {
+    const int B = 5;
+    if (pen->x < B || pen->o1 + pen->e1 < B || pen->e1 != 2) return 0;
+    if (pen->two && (pen->o2 + pen->e2 < B || pen->e2 != 1)) return 0;
+    if (ori->two || ori->e1 != 1) return 0;
+    if (pen->scope + B + 1 > BFS_MAK_SLOTS || ori->scope + 2 > BFS_MAK_SLOTS) return 0;
+    return B;
+}
+extern "C" int srk_align_blk(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, int nthreads, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (off16) {
+        if (nthreads == 128) return a->pen.two ? launch_blk3<int16_t, 128, true>(a, nwg, lds_bytes, st) : launch_blk3<int16_t, 128, false>(a, nwg, lds_bytes, st);
+        if (nthreads == 512) return a->pen.two ? launch_blk3<int16_t, 512, true>(a, nwg, lds_bytes, st) : launch_blk3<int16_t, 512, false>(a, nwg, lds_bytes, st);
+        return a->pen.two ? launch_blk3<int16_t, 256, true>(a, nwg, lds_bytes, st) : launch_blk3<int16_t, 256, false>(a, nwg, lds_bytes, st);
+    }
+    return a->pen.two ? launch_blk3<int32_t, 256, true>(a, nwg, lds_bytes, st) : launch_blk3<int32_t, 256, false>(a, nwg, lds_bytes, st);
+}

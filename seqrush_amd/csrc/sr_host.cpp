@@ -373,13 +373,16 @@ extern "C" int sr_ctx_load(sr_ctx *c, const sr_seqset *seqs, const sr_params *p)
     if ((long long)c->lds_bytes > (long long)srk_align_max_lds())
         return fail(SR_ERR_UNSUPPORTED, "sequences too long to stage in LDS (limit ~ 200 kb per sequence)");
     // implementation: 1 = level-synchronous ("bfs") kernel, 0 = one-segment-at-a-time kernel
+    // 2 = score-blocked wave-tiled kernel (when this build has an instance for the penalties)
     int impl = (std::max(pen.scope, ori.scope) + 1 <= 32) ? 1 : 0;
-    if (const char *e = getenv("SR_ALIGN_IMPL")) impl = atoi(e) ? impl : 0;
+    const int kblock = srk_align_blk_supports(&pen, &ori);
+    if (impl && kblock > 0) impl = 2;
+    if (const char *e = getenv("SR_ALIGN_IMPL")) impl = std::min(impl, std::max(0, atoi(e)));
     int wg_per_cu = impl ? 4 : 8;
     if (const char *e = getenv("SR_WG_PER_CU")) wg_per_cu = std::max(1, atoi(e));
     c->nthreads = impl ? 256 : 128;
     if (const char *e = getenv("SR_ALIGN_THREADS")) { int v = atoi(e); if (impl ? (v == 128 || v == 256 || v == 512) : (v == 64 || v == 128 || v == 256)) c->nthreads = v; }
-    const size_t lds_per_wg = c->lds_bytes + (impl ? 28 : 8) * 1024;
+    const size_t lds_per_wg = c->lds_bytes + (impl == 2 ? 36 : impl ? 28 : 8) * 1024;
     wg_per_cu = (int)std::min<size_t>((size_t)wg_per_cu, std::max<size_t>(1, (160 * 1024) / lds_per_wg));
     const int ring_scope = std::max(pen.scope, ori.scope);
     const int ring_cap = (int)((2 * maxlen + 3 + 7) & ~7ULL);
@@ -392,19 +395,21 @@ extern "C" int sr_ctx_load(sr_ctx *c, const sr_seqset *seqs, const sr_params *p)
     const int gapmax = pen.two ? std::max(pen.o1, pen.o2) : pen.o1;
     auto gc = [&](int len) { int g = pen.o1 + pen.e1 * len; if (pen.two) g = std::min(g, pen.o2 + pen.e2 * len); return g; };
     const int smax_base = std::max(250 + gapmax, 2 * gc(100)) + 2 * gapmax + 4;
-    const int hist_levels = smax_base + 1;
+    const int hist_levels = smax_base + 1 + 5;          // + one block of levels (impl 2 computes whole blocks)
     int rmax = smax_base / pen.e1;
     if (pen.two) rmax = std::max(rmax, smax_base / pen.e2);
-    const int hist_w = (2 * (rmax + pen.scope + 2) + 1 + 8 + 7) & ~7;   // rows hold whole 4-diagonal groups
+    const int hist_w = (2 * (rmax + pen.scope + 2) + 1 + 8 + 32 + 7) & ~7;   // rows hold whole 4-diagonal groups
     const uint64_t hist_wg = (uint64_t)hist_levels * 5 * (uint64_t)hist_w + (uint64_t)hist_w;   // + NULL row
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
     // bfs kernel workspace: shared rows (every aligner owns a sub-range) + batched base-case history
-    const int brow = (int)((4 * maxlen + 16 * 64 + 64 + 7) & ~7ULL);
-    const uint64_t bring_wg = ((uint64_t)(ring_scope + 1) + 4ULL * ring_hot + 4ULL * (ring_scope + 1) + 2ULL) * (uint64_t)brow;   // + NULL row + U row
+    const int brow = (int)((4 * maxlen + 32 * 64 + 64 + 512 + 7) & ~7ULL);     // per-aligner margins + read slack of the last wave tile
+    const int kdepth = std::max(pen.scope + std::max(kblock, 1), ori.scope + 1) + 1;
+    uint64_t bring_wg = ((uint64_t)(ring_scope + 1) + 4ULL * ring_hot + 4ULL * (ring_scope + 1) + 2ULL) * (uint64_t)brow;   // + NULL row + U row
+    if (impl == 2) bring_wg = ((uint64_t)kdepth * 5 + 2ULL) * (uint64_t)brow + 1024;
     int bbase_jobs = 16;
     if (const char *e = getenv("SR_BFS_BASE_JOBS")) bbase_jobs = std::max(1, std::min(16, atoi(e)));
-    const uint64_t bhist_wg = ((uint64_t)hist_levels * 5 + 1) * (uint64_t)bbase_jobs * (uint64_t)hist_w;
+    const uint64_t bhist_wg = ((uint64_t)hist_levels * 5 + 1) * (uint64_t)bbase_jobs * (uint64_t)hist_w + 1024;
     const uint64_t bseg_wg = 2ULL * SR_BFS_MAXSEG * SR_BFS_SEGREC * 4;          // bytes
     const uint64_t bbt_wg = (uint64_t)bbase_jobs * SR_BFS_BTCAP * 4;           // bytes
     const uint64_t per_wg_bytes = impl ? (bring_wg + bhist_wg) * osz + bseg_wg + bbt_wg : (ring_wg + hist_wg) * osz;
@@ -468,7 +473,7 @@ extern "C" int sr_ctx_load(sr_ctx *c, const sr_seqset *seqs, const sr_params *p)
     a.queue_head = c->d_queue; a.pen = pen; a.ori = ori; a.mem_mode = p->memory_mode;
     a.ring_wg_stride = ring_wg; a.ring_dir_stride = ring_dir; a.ring_cap = ring_cap; a.ring_scope = ring_scope; a.ring_hot = ring_hot;
     a.hist_wg_stride = hist_wg; a.hist_w = hist_w; a.hist_levels = hist_levels;
-    a.impl = impl; a.bring_wg_stride = bring_wg; a.brow = brow; a.bhist_wg_stride = bhist_wg; a.bbase_jobs = bbase_jobs;
+    a.impl = impl; a.kdepth = kdepth; a.bring_wg_stride = bring_wg; a.brow = brow; a.bhist_wg_stride = bhist_wg; a.bbase_jobs = bbase_jobs;
     a.cigar_base = d_cbase; a.counters = c->d_counters; a.error_flag = c->d_error;
     SrUniteArgs &u = c->ua;
     memset(&u, 0, sizeof(u));

@@ -60,7 +60,9 @@ struct SrAlignArgs {
     uint64_t hist_wg_stride;
     int hist_w, hist_levels;
     // level-synchronous ("bfs") kernel workspace, per workgroup
-    int impl;                  // 0 = one segment at a time (sr_align_kernel), 1 = sr_align_bfs_kernel
+    int impl;                  // 0 = one segment at a time (sr_align_kernel), 1 = sr_align_bfs_kernel,
+                               // 2 = sr_align_blk_kernel (rows: [kdepth][5 components] | NULL row | U row)
+    int kdepth;                // ring depth of impl 2 (scope + levels per block + 1)
     void *bring;               // rows of brow offsets: M[(ring_scope+1)] | hot I1 I2 D1 D2 [ring_hot] each |
                                //   cold [(ring_scope+1)][4] | NULL row ; every aligner owns a sub-range of each row
     uint64_t bring_wg_stride;
@@ -111,6 +113,7 @@ int srk_labels(unsigned long long *nodes, uint64_t uf_size, unsigned long long *
 int srk_merge(unsigned long long *nodes, uint64_t uf_size, const unsigned long long *labels,
               uint32_t count, int *error_flag, void *stream);
 int srk_align_max_lds(void);
+int srk_align_blk_supports(const SrPen *pen, const SrPen *ori);   // levels per block, 0 = no blocked instance
 #ifdef __cplusplus
 }
 #endif

@@ -199,8 +199,10 @@ __global__ void sr_merge_kernel(unsigned long long *nodes, unsigned long long n,
 
 extern "C" int srk_align_v3(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, int nthreads, void *stream);
 extern "C" int srk_align_bfs(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, int nthreads, void *stream);
+extern "C" int srk_align_blk(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, int nthreads, void *stream);
 
 extern "C" int srk_align(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, int nthreads, void *stream) {
+    if (a->impl == 2) return srk_align_blk(a, nwg, lds_bytes, off16, nthreads, stream);
     if (a->impl == 1) return srk_align_bfs(a, nwg, lds_bytes, off16, nthreads, stream);
     return srk_align_v3(a, nwg, lds_bytes, off16, nthreads, stream);
 }
