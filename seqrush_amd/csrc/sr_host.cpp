@@ -369,15 +369,17 @@ extern "C" int sr_ctx_load(sr_ctx *c, const sr_seqset *seqs, const sr_params *p)
     c->off16 = maxlen <= 32000 ? 1 : 0;
     const size_t osz = c->off16 ? 2 : 4;
     const uint32_t max_words = (uint32_t)((maxlen + 15) / 16 + 2);
-    c->lds_bytes = (size_t)max_words * 3 * 4;
+    c->lds_bytes = (size_t)max_words * 3 * 4;          // query fwd / rc + target fwd
     if ((long long)c->lds_bytes > (long long)srk_align_max_lds())
         return fail(SR_ERR_UNSUPPORTED, "sequences too long to stage in LDS (limit ~ 200 kb per sequence)");
     // implementation: 1 = level-synchronous ("bfs") kernel, 0 = one-segment-at-a-time kernel
     // 2 = score-blocked wave-tiled kernel (when this build has an instance for the penalties)
     int impl = (std::max(pen.scope, ori.scope) + 1 <= 32) ? 1 : 0;
     const int kblock = srk_align_blk_supports(&pen, &ori);
-    if (impl && kblock > 0) impl = 2;
+    // impl 2 also stages the target's reverse complement (4 regions) and has ~36 KB of static LDS
+    if (impl && kblock > 0 && (long long)max_words * 16 + 40 * 1024 <= 160 * 1024) impl = 2;
     if (const char *e = getenv("SR_ALIGN_IMPL")) impl = std::min(impl, std::max(0, atoi(e)));
+    if (impl == 2) c->lds_bytes = (size_t)max_words * 4 * 4;
     int wg_per_cu = impl ? 4 : 8;
     if (const char *e = getenv("SR_WG_PER_CU")) wg_per_cu = std::max(1, atoi(e));
     c->nthreads = impl ? 256 : 128;
