@@ -2,7 +2,7 @@
 #include "sr_dev_common.h"
 #include "sr_align_bfs.inc"
 #ifndef SR_BLK_MIN_WAVES
-#define SR_BLK_MIN_WAVES 2
+#define SR_BLK_MIN_WAVES 4
 #endif
 #include "sr_align_blk.inc"
 

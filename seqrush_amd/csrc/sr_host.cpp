@@ -384,7 +384,7 @@ extern "C" int sr_ctx_load(sr_ctx *c, const sr_seqset *seqs, const sr_params *p)
     if (const char *e = getenv("SR_WG_PER_CU")) wg_per_cu = std::max(1, atoi(e));
     c->nthreads = impl ? 256 : 128;
     if (const char *e = getenv("SR_ALIGN_THREADS")) { int v = atoi(e); if (impl ? (v == 128 || v == 256 || v == 512) : (v == 64 || v == 128 || v == 256)) c->nthreads = v; }
-    const size_t lds_per_wg = c->lds_bytes + (impl == 2 ? 36 : impl ? 28 : 8) * 1024;
+    const size_t lds_per_wg = c->lds_bytes + (impl == 2 ? 34 : impl ? 28 : 8) * 1024;
     wg_per_cu = (int)std::min<size_t>((size_t)wg_per_cu, std::max<size_t>(1, (160 * 1024) / lds_per_wg));
     const int ring_scope = std::max(pen.scope, ori.scope);
     const int ring_cap = (int)((2 * maxlen + 3 + 7) & ~7ULL);
@@ -414,7 +414,9 @@ extern "C" int sr_ctx_load(sr_ctx *c, const sr_seqset *seqs, const sr_params *p)
     const uint64_t bhist_wg = ((uint64_t)hist_levels * 5 + 1) * (uint64_t)bbase_jobs * (uint64_t)hist_w + 1024;
     const uint64_t bseg_wg = 2ULL * SR_BFS_MAXSEG * SR_BFS_SEGREC * 4;          // bytes
     const uint64_t bbt_wg = (uint64_t)bbase_jobs * SR_BFS_BTCAP * 4;           // bytes
-    const uint64_t per_wg_bytes = impl ? (bring_wg + bhist_wg) * osz + bseg_wg + bbt_wg : (ring_wg + hist_wg) * osz;
+    // impl 2: every diagonal of every level of a block can be a breakpoint candidate at worst
+    const uint64_t bcl_wg = (impl == 2) ? (uint64_t)std::max(kblock, 1) * (uint64_t)brow : 0;
+    const uint64_t per_wg_bytes = impl ? (bring_wg + bhist_wg) * osz + bseg_wg + bbt_wg + bcl_wg * 4 : (ring_wg + hist_wg) * osz;
     uint64_t budget = (uint64_t)(free_b * 0.6);
     int nwg = cus * wg_per_cu;
     if ((uint64_t)nwg > np) nwg = (int)np;
@@ -451,6 +453,7 @@ extern "C" int sr_ctx_load(sr_ctx *c, const sr_seqset *seqs, const sr_params *p)
         if ((r = dev_alloc(c, &d, (uint64_t)nwg * bhist_wg * osz))) return r; a.bhist = d;
         if ((r = dev_alloc(c, &d, (uint64_t)nwg * bseg_wg))) return r; a.bseg = (int *)d;
         if ((r = dev_alloc(c, &d, (uint64_t)nwg * bbt_wg))) return r; a.bbt = (uint32_t *)d;
+        if (bcl_wg) { if ((r = dev_alloc(c, &d, (uint64_t)nwg * bcl_wg * 4))) return r; a.bcl = (uint32_t *)d; a.bcl_wg_stride = bcl_wg; }
     } else {
         if ((r = dev_alloc(c, &d, (uint64_t)nwg * ring_wg * osz))) return r; a.ring = d;
         if ((r = dev_alloc(c, &d, (uint64_t)nwg * hist_wg * osz))) return r; a.hist = d;

@@ -72,6 +72,8 @@ struct SrAlignArgs {
     int bbase_jobs;
     int *bseg;                 // 2 segment lists of SR_BFS_MAXSEG records x SR_BFS_SEGREC ints
     uint32_t *bbt;             // [bbase_jobs][SR_BFS_BTCAP] reversed run-length ops of finished base cases
+    uint32_t *bcl;             // impl 2: breakpoint candidate list, bcl_wg_stride entries per workgroup
+    uint64_t bcl_wg_stride;
     // outputs
     uint8_t *is_reverse;       // [npairs]
     int32_t *score;            // [npairs]
