@@ -1,5 +1,6 @@
 // sr_align_blk.hip -- translation unit of the score-blocked, wave-tiled biWFA kernel (see sr_align_blk.inc)
 #include "sr_dev_common.h"
+#define SR_BLK_TU 1
 #include "sr_align_bfs.inc"
 #ifndef SR_BLK_MIN_WAVES
 #define SR_BLK_MIN_WAVES 4
