@@ -160,9 +160,7 @@ def main():
         cells = cnt["wf_cells"]
         alg_bytes = cells * BYTES_PER_CELL_2P + ctx.num_pairs * (2 * 1250 * 2 + 8 * 1024)
         achieved = alg_bytes / (a_ms * 1e-3) / 1e9
-        # SR_ALIGN_IMPL=0 selects the older per-WG pair kernel; default is the level-synchronous one
-        align_kernel_name = ("sr_align_kernel" if os.environ.get("SR_ALIGN_IMPL") == "0"
-                             else "sr_align_bfs_kernel")
+        align_kernel_name = ctx.align_kernel
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
         if world == 1 and os.path.exists(tpath):

@@ -164,11 +164,15 @@ int sr_ctx_download_labels(sr_ctx *c, uint64_t *labels_out);
 /* timing of the last enqueued kernels, measured with hipEvents on the
  * context's stream: which = 0 align, 1 unite, 2 labels/merge */
 int sr_ctx_kernel_ms(sr_ctx *c, int which, float *ms);
+/* name of the alignment kernel the loaded context launches ("sr_align_blk_kernel",
+ * "sr_align_bfs_kernel" or "sr_align_kernel"), NULL before sr_ctx_load */
+const char *sr_ctx_align_kernel(const sr_ctx *c);
 /* device counters accumulated by the last align: [0] wavefront cells,
  * [1] wavefront steps, [2] base-case segments, [3] breakpoint searches,
- * [4] united bases (after unite), [5] match runs, [6..10] 100 MHz ticks summed
- * over workgroups: orientation, breakpoint search, base cases, top-level
- * breakpoint search, whole pair */
+ * [4] united bases (after unite), [5] match runs, [6..8] 100 MHz ticks summed
+ * over workgroups: orientation, breakpoint search, base cases; [9] breakpoint-
+ * search passes; [10] ticks of whole pairs; [11..15] ticks inside the breakpoint
+ * search: wavefront pass, barrier wait, phase-1 control, breakpoint detection, tail */
 int sr_ctx_counters(sr_ctx *c, uint64_t out[16]);
 
 /* -------- consumer (A9): graph induction + GFA, host C++ -----------------

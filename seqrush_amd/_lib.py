@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libseqrush_amd.so")
+# SEQRUSH_AMD_LIB: another build of the same library (kernel A/B experiments)
+LIB_PATH = os.environ.get("SEQRUSH_AMD_LIB") or os.path.join(_HERE, "libseqrush_amd.so")
 
 # every symbol include/seqrush_amd.h declares
 EXPORTS = [
@@ -19,7 +20,7 @@ EXPORTS = [
     "sr_ctx_unite", "sr_ctx_sync", "sr_ctx_alignments", "sr_ctx_download_uf", "sr_ctx_uf_size",
     "sr_ctx_num_pairs", "sr_ctx_dp_cells", "sr_ctx_labels_device", "sr_ctx_merge_labels",
     "sr_ctx_download_labels", "sr_ctx_kernel_ms", "sr_ctx_counters", "sr_build_gfa", "sr_free",
-    "sr_last_error", "sr_abi_version", "sr_device_count", "sr_pair_list",
+    "sr_last_error", "sr_abi_version", "sr_device_count", "sr_pair_list", "sr_ctx_align_kernel",
 ]
 
 
@@ -100,6 +101,7 @@ def load():
     L.sr_ctx_merge_labels.argtypes = [vp, vp, C.c_uint32]
     L.sr_ctx_download_labels.argtypes = [vp, C.POINTER(u64)]
     L.sr_ctx_kernel_ms.argtypes = [vp, i32, C.POINTER(C.c_float)]
+    L.sr_ctx_align_kernel.argtypes = [vp]; L.sr_ctx_align_kernel.restype = C.c_char_p
     L.sr_ctx_counters.argtypes = [vp, C.POINTER(u64)]
     L.sr_build_gfa.argtypes = [PS, C.POINTER(u64), C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
     L.sr_pair_list.argtypes = [C.c_uint32, PP, C.POINTER(C.POINTER(C.c_uint32)),

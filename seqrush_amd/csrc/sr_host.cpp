@@ -550,6 +550,11 @@ extern "C" uint64_t sr_ctx_uf_size(const sr_ctx *c) { return c ? c->uf_size : 0;
 extern "C" uint64_t sr_ctx_num_pairs(const sr_ctx *c) { return c ? c->pair_q.size() : 0; }
 extern "C" uint64_t sr_ctx_dp_cells(const sr_ctx *c) { return c ? c->dp_cells : 0; }
 
+extern "C" const char *sr_ctx_align_kernel(const sr_ctx *c) {
+    if (!c || !c->loaded) return nullptr;
+    return c->aa.impl == 2 ? "sr_align_blk_kernel" : c->aa.impl == 1 ? "sr_align_bfs_kernel" : "sr_align_kernel";
+}
+
 extern "C" int sr_ctx_kernel_ms(sr_ctx *c, int which, float *ms) {
     if (!c || which < 0 || which > 2 || !c->ev_valid[which]) return fail(SR_ERR_INVALID, "no timing recorded");
     HIPCHK(hipEventSynchronize(c->ev[which][1]));

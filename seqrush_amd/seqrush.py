@@ -286,6 +286,11 @@ class Context:
     def merge_labels(self, dev_ptr: int, count: int):
         check(self.L.sr_ctx_merge_labels(self._h, C.c_void_p(dev_ptr), count))
 
+    @property
+    def align_kernel(self) -> str:
+        n = self.L.sr_ctx_align_kernel(self._h)
+        return n.decode() if n else ""
+
     def kernel_ms(self, which: int) -> float:
         ms = C.c_float()
         check(self.L.sr_ctx_kernel_ms(self._h, which, C.byref(ms)))

@@ -45,6 +45,7 @@ def run_gpu(recs, **kw):
     nodes = ctx.download_uf()
     ctx.sync()
     cnt = ctx.counters()
+    cnt["align_kernel"] = ctx.align_kernel
     ctx.close()
     return ss, al, labels, nodes, cnt
 
@@ -298,15 +299,33 @@ def test_run_seqrush_cli_end_to_end(gpu, tmp_path, capsys):
     assert main(["-s", str(empty), "-o", str(out), "--no-sort", "--no-compact"]) == 1
 
 
-@pytest.mark.parametrize("impl,threads", [("0", "128"), ("0", "256"), ("1", "128"), ("1", "512")])
-def test_both_align_kernels_and_workgroup_sizes(gpu, impl, threads, monkeypatch):
-    """sr_align_kernel (one segment at a time, SR_ALIGN_IMPL=0) and sr_align_bfs_kernel (level-synchronous,
-    default) implement the same rules: both must match the oracle bit for bit, at every workgroup size"""
+KERNELS = {"0": "sr_align_kernel", "1": "sr_align_bfs_kernel", "2": "sr_align_blk_kernel"}
+
+
+@pytest.mark.parametrize("impl,threads", [("0", "128"), ("0", "256"), ("1", "128"), ("1", "512"),
+                                          ("2", "128"), ("2", "256"), ("2", "512")])
+def test_all_align_kernels_and_workgroup_sizes(gpu, impl, threads, monkeypatch):
+    """sr_align_kernel (one segment at a time, SR_ALIGN_IMPL=0), sr_align_bfs_kernel (level-synchronous, =1)
+    and sr_align_blk_kernel (score-blocked wave tiles, default) implement the same rules: each must match
+    the oracle bit for bit, at every workgroup size"""
     monkeypatch.setenv("SR_ALIGN_IMPL", impl)
     monkeypatch.setenv("SR_ALIGN_THREADS", threads)
-    check_parity(synth.indel_family(4, 1500, 0.04, 0.015, 131))
+    _, _, cnt = check_parity(synth.indel_family(4, 1500, 0.04, 0.015, 131))
+    assert cnt["align_kernel"] == KERNELS[impl]
     check_parity(synth.snp_family(4, 900, 0.06, 132, rc_every=2))
-    check_parity([("p", b"ATCGATCG"), ("t", b"ATCGATCGATCG")], scores="0,5,8,2")
+    _, _, cnt = check_parity([("p", b"ATCGATCG"), ("t", b"ATCGATCGATCG")], scores="0,5,8,2")
+    assert cnt["align_kernel"] == KERNELS[impl]            # one-piece 0,5,8,2 has a blocked instance too
+
+
+def test_penalties_without_blocked_instance_fall_back(gpu):
+    """the blocked kernel is instantiated for gap-extend (2, 1) and blocks of 5 levels; other penalty sets
+    run on the level-synchronous kernel and must match the oracle just the same"""
+    recs = synth.indel_family(3, 1200, 0.05, 0.02, 141)
+    for scores in ("0,4,6,2,24,1", "0,6,9,3,24,1", "0,5,8,1", "0,7,10,2,24,2"):
+        _, _, cnt = check_parity(recs, scores=scores)
+        assert cnt["align_kernel"] == "sr_align_bfs_kernel", scores
+    _, _, cnt = check_parity(recs, scores="0,6,5,2,20,1")          # x >= 5, o1+e1 >= 5, e = (2, 1): blocked
+    assert cnt["align_kernel"] == "sr_align_blk_kernel"
 
 
 @pytest.mark.parametrize("name,recs,kw", [
