@@ -161,6 +161,14 @@ uint64_t sr_ctx_dp_cells(const sr_ctx *c);   /* sum |q|*|t| over this shard */
 int sr_ctx_labels_device(sr_ctx *c, uint64_t *dev_labels);
 int sr_ctx_merge_labels(sr_ctx *c, const uint64_t *dev_labels, uint32_t count);
 int sr_ctx_download_labels(sr_ctx *c, uint64_t *labels_out);
+/* Seam 3, input side (`seqrush -p file.paf`, src/seqrush.rs:510-609): replaces sr_ctx_load + sr_ctx_align.
+ * Every record of the PAF file whose names are known and that carries a cg:Z: tag is replayed through
+ * process_alignment's rules (src/seqrush.rs:1134-1481: bases of M/= ops are compared, runs >= min_match_len
+ * are united, query_start/target_start honoured, strand '-' = reverse-complemented query); follow with
+ * sr_ctx_unite.  Records are sharded over ranks like the pair list.  sr_unite_paf is the fused form of
+ * load + unite + download (raw uf_rush nodes, or canonical labels with p->canonical_labels). */
+int sr_ctx_load_paf(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const char *paf_path);
+int sr_unite_paf(const sr_seqset *seqs, const sr_params *p, const char *paf_path, uint64_t *parent_out);
 /* timing of the last enqueued kernels, measured with hipEvents on the
  * context's stream: which = 0 align, 1 unite, 2 labels/merge */
 int sr_ctx_kernel_ms(sr_ctx *c, int which, float *ms);

@@ -42,7 +42,7 @@ static bool load_sequences(const std::string &path, std::vector<Seq> &out) {
 
 static void usage() {
     fprintf(stderr, "usage: seqrush_mi355x -s in.fa [-o output.gfa] [-k 0] [-S 0,5,8,2,24,1] [--orientation-scores 0,1,1,1]\n"
-                    "       [-d max_divergence] [-x none|random:F] [--output-alignments out.paf] --no-sort --no-compact [--device N]\n");
+                    "       [-d max_divergence] [-x none|random:F] [-p in.paf] [--output-alignments out.paf] --no-sort --no-compact [--device N]\n");
 }
 
 int main(int argc, char **argv) {
@@ -76,7 +76,6 @@ int main(int argc, char **argv) {
         else { usage(); return 2; }
     }
     if (sequences.empty()) { usage(); return 2; }
-    if (!paf_in.empty()) { fprintf(stderr, "Error: -p/--paf input is not implemented (next row of the scope table)\n"); return 1; }
     if (aligner != "allwave" && aligner != "AllWave") { fprintf(stderr, "Error: aligner '%s' is out of scope; only 'allwave'\n", aligner.c_str()); return 1; }
     if (!(no_sort && no_compact)) { fprintf(stderr, "Error: only --no-sort --no-compact output is implemented\n"); return 1; }
     std::vector<Seq> seqs;
@@ -97,7 +96,7 @@ int main(int argc, char **argv) {
     p.min_match_len = (uint64_t)k; p.max_divergence = max_div; p.device = device; p.canonical_labels = 1;
     printf("Building graph with %zu sequences (total length: %zu)\n", seqs.size(), bases.size());
     printf("Total sequence pairs: %zu (sparsification: %s)\n", seqs.size() * seqs.size(), sparsify.c_str());
-    if (!paf_out.empty()) {
+    if (!paf_out.empty() && paf_in.empty()) {
         sr_alignments *al = nullptr;
         if (sr_align_all(&set, &p, &al)) { fprintf(stderr, "Error: %s\n", sr_last_error()); return 1; }
         printf("Writing alignments to %s\n", paf_out.c_str());
@@ -105,7 +104,10 @@ int main(int argc, char **argv) {
         sr_alignments_free(al);
     }
     std::vector<uint64_t> labels(2 * bases.size() + 2);
-    if (sr_align_and_unite(&set, &p, labels.data())) { fprintf(stderr, "Error: %s\n", sr_last_error()); return 1; }
+    if (!paf_in.empty()) {                                   // align_and_unite_from_paf (src/seqrush.rs:510-609)
+        printf("Reading alignments from PAF file: %s\n", paf_in.c_str());
+        if (sr_unite_paf(&set, &p, paf_in.c_str(), labels.data())) { fprintf(stderr, "Error: %s\n", sr_last_error()); return 1; }
+    } else if (sr_align_and_unite(&set, &p, labels.data())) { fprintf(stderr, "Error: %s\n", sr_last_error()); return 1; }
     char *gfa = nullptr;
     uint64_t nn = 0, ne = 0;
     if (sr_build_gfa(&set, labels.data(), &gfa, &nn, &ne)) { fprintf(stderr, "Error: %s\n", sr_last_error()); return 1; }

@@ -171,6 +171,7 @@ struct sr_ctx {
     hipEvent_t ev[3][2]{};
     bool ev_valid[3] = {false, false, false};
     bool loaded = false;
+    bool from_paf = false;             // loaded by sr_ctx_load_paf: no alignment stage, no sr_alignments
 };
 
 static int dev_alloc(sr_ctx *c, void **p, size_t bytes) {
@@ -183,7 +184,7 @@ static void free_dev(sr_ctx *c) {
     c->dev_allocs.clear();
     c->d_nodes = c->d_minarr = c->d_labels = c->d_counters = nullptr;
     c->d_error = nullptr; c->d_queue = nullptr; c->d_max_score = nullptr;
-    c->loaded = false;
+    c->loaded = false; c->from_paf = false;
 }
 
 extern "C" int sr_ctx_create(int device, sr_ctx **out) {
@@ -551,7 +552,7 @@ extern "C" uint64_t sr_ctx_num_pairs(const sr_ctx *c) { return c ? c->pair_q.siz
 extern "C" uint64_t sr_ctx_dp_cells(const sr_ctx *c) { return c ? c->dp_cells : 0; }
 
 extern "C" const char *sr_ctx_align_kernel(const sr_ctx *c) {
-    if (!c || !c->loaded) return nullptr;
+    if (!c || !c->loaded || c->from_paf) return nullptr;
     return c->aa.impl == 2 ? "sr_align_blk_kernel" : c->aa.impl == 1 ? "sr_align_bfs_kernel" : "sr_align_kernel";
 }
 
@@ -616,6 +617,7 @@ extern "C" void sr_alignments_free(sr_alignments *a) {
 
 extern "C" int sr_ctx_alignments(sr_ctx *c, sr_alignments **out) {
     if (!c || !c->loaded) return fail(SR_ERR_INVALID, "context not loaded");
+    if (c->from_paf) return fail(SR_ERR_INVALID, "context was loaded from a PAF file: it holds no device alignments");
     int r = sr_ctx_sync(c);
     if (r) return r;
     const size_t np = c->pair_q.size();
@@ -689,6 +691,190 @@ extern "C" int sr_align_and_unite(const sr_seqset *seqs, const sr_params *p, uin
     int r = sr_ctx_create(p->device, &c);
     if (r) return r;
     if (!(r = sr_ctx_load(c, seqs, p)) && !(r = sr_ctx_align(c)) && !(r = sr_ctx_unite(c)) && !(r = sr_ctx_sync(c))) {
+        if (p->canonical_labels) r = sr_ctx_download_labels(c, parent_out);
+        else r = sr_ctx_download_uf(c, parent_out);
+        if (!r) r = sr_ctx_sync(c);
+    }
+    std::string keep = g_err;
+    sr_ctx_destroy(c);
+    g_err = keep;
+    return r;
+}
+
+
+// ------------------------------------------------------------------ PAF input (seam 3, `seqrush -p`)
+// SeqRush::align_and_unite_from_paf (src/seqrush.rs:510-609) + process_alignment (:1134-1481): every PAF
+// record with a cg:Z: tag is replayed.  The host walks the CIGAR once and compares the bases of M / = ops
+// (the reference does, :1268-1330), producing exact-match / mismatch runs in the device op alphabet; runs of
+// consecutive M/= ops merge, so `len >= k` sees the same run lengths.  The records then go through the same
+// sr_unite_kernel as device-made alignments, starting at (query_start, target_start); for strand '-' the
+// query offset is in reverse-complement space like in the reference (:1210, 1165).
+static inline uint8_t paf_query_base(const uint8_t *q, uint64_t qlen, bool rc, uint64_t pos) {   // :1162-1176
+    return rc ? comp_base(q[qlen - 1 - pos]) : q[pos];
+}
+
+extern "C" int sr_ctx_load_paf(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const char *paf_path) {
+    if (!c || !seqs || !p || !paf_path) return fail(SR_ERR_INVALID, "null argument");
+    if (seqs->n == 0) return fail(SR_ERR_INVALID, "no sequences");
+    if (!seqs->names) return fail(SR_ERR_INVALID, "PAF input needs sequence names");
+    if (p->shard_count == 0 || p->shard_rank >= p->shard_count) return fail(SR_ERR_INVALID, "bad shard");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    free_dev(c);
+    c->prm = *p;
+    const uint32_t n = seqs->n;
+    c->n = n;
+    c->len.assign(n, 0); c->goff.assign(n, 0);
+    std::unordered_map<std::string, uint32_t> by_name;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint64_t L = seqs->offsets[i + 1] - seqs->offsets[i];
+        std::string nm = seqs->names[i] ? seqs->names[i] : "";
+        if (L == 0) return fail(SR_ERR_EMPTY_SEQ, "Empty sequences are not allowed: sequence '" + nm + "' has length 0");
+        if (L > 0x7fff0000ULL) return fail(SR_ERR_UNSUPPORTED, "sequence too long");
+        c->len[i] = (uint32_t)L; c->goff[i] = seqs->offsets[i];
+        by_name[nm] = i;                                   // HashMap collect: a later duplicate id wins (:517-522)
+    }
+    c->total_len = seqs->offsets[n];
+    c->uf_size = (c->total_len << 1) + 2;
+    FILE *f = fopen(paf_path, "r");
+    if (!f) return fail(SR_ERR_IO, std::string("Failed to open PAF file ") + paf_path);
+    std::vector<uint32_t> ops, qs, ts;
+    std::vector<uint8_t> isrev;
+    c->pair_q.clear(); c->pair_t.clear();
+    c->cigar_base.assign(1, 0);
+    std::string line;
+    std::vector<char> buf(1 << 16);
+    uint64_t recno = 0;
+    int rc_err = SR_OK;
+    auto getline_all = [&](std::string &out) -> bool {
+        out.clear();
+        while (fgets(buf.data(), (int)buf.size(), f)) {
+            out += buf.data();
+            if (!out.empty() && out.back() == '\n') { out.pop_back(); if (!out.empty() && out.back() == '\r') out.pop_back(); return true; }
+        }
+        return !out.empty();
+    };
+    auto to_u64 = [&](const std::string &t, uint64_t &v) -> bool {
+        if (t.empty()) return false;
+        v = 0;
+        for (char ch : t) { if (ch < '0' || ch > '9') return false; v = v * 10 + (uint64_t)(ch - '0'); }
+        return true;
+    };
+    while (getline_all(line)) {
+        if (line.empty()) continue;                                              // :529-531
+        std::vector<std::string> fld;
+        size_t b = 0;
+        for (;;) { size_t e = line.find('\t', b); fld.push_back(line.substr(b, e == std::string::npos ? e : e - b)); if (e == std::string::npos) break; b = e + 1; }
+        if (fld.size() < 12) continue;                                           // warning + skip (:534-537)
+        uint64_t ql, qb, qe, tl, tb, te;
+        if (!to_u64(fld[1], ql) || !to_u64(fld[2], qb) || !to_u64(fld[3], qe) || !to_u64(fld[6], tl) ||
+            !to_u64(fld[7], tb) || !to_u64(fld[8], te)) {                        // .parse().unwrap() panics (:541-548)
+            rc_err = fail(SR_ERR_INVALID, "PAF line with a non-numeric coordinate: " + line.substr(0, 80));
+            break;
+        }
+        std::string cigar;
+        for (size_t i = 12; i < fld.size(); i++) if (fld[i].compare(0, 5, "cg:Z:") == 0) { cigar = fld[i].substr(5); break; }
+        auto iq = by_name.find(fld[0]), it = by_name.find(fld[5]);
+        if (iq == by_name.end() || it == by_name.end()) continue;                // warning + skip (:570-576)
+        const uint64_t my = recno++;
+        if (my % p->shard_count != p->shard_rank) continue;
+        const uint32_t q = iq->second, t = it->second;
+        const bool rc = fld[4] == "-";
+        if (qb > 0xffffffffULL || tb > 0xffffffffULL) { rc_err = fail(SR_ERR_INVALID, "PAF start coordinate out of range"); break; }
+        const uint8_t *Q = seqs->bases + seqs->offsets[q], *T = seqs->bases + seqs->offsets[t];
+        const uint64_t len1 = c->len[q], len2 = c->len[t];
+        uint64_t pos1 = qb, pos2 = tb, count = 0;
+        const size_t first = ops.size();
+        auto push = [&](int op, uint64_t len) {
+            while (len > 0) {
+                const uint64_t chunk = std::min<uint64_t>(len, (1u << 27));
+                if (ops.size() > first && (ops.back() & 15u) == (uint32_t)op && (ops.back() >> 4) + chunk < (1u << 28)) ops.back() += (uint32_t)chunk << 4;
+                else ops.push_back(((uint32_t)chunk << 4) | (uint32_t)op);
+                len -= chunk;
+            }
+        };
+        bool bad = false;
+        for (char ch : cigar) {
+            if (ch >= '0' && ch <= '9') { count = count * 10 + (uint64_t)(ch - '0'); continue; }
+            if (count == 0) count = 1;                                           // :1251-1253
+            if (ch == 'M' || ch == '=') {
+                for (uint64_t k = 0; k < count; k++) {
+                    if (pos1 + k < len1 && pos2 + k < len2) {                    // :1268
+                        if (paf_query_base(Q, len1, rc, pos1 + k) == T[pos2 + k]) push(SR_OP_M, 1);
+                        else push(SR_OP_X, 1);
+                    } else push(SR_OP_X, 1);    // past an end: never a match again (positions only grow); keeps offsets
+                }
+                pos1 += count; pos2 += count;
+            } else if (ch == 'X') { push(SR_OP_X, count); pos1 += count; pos2 += count; }
+            else if (ch == 'I') { push(SR_OP_D, count); pos1 += count; }         // PAF I = query only = raw D (:1420-1426)
+            else if (ch == 'D') { push(SR_OP_I, count); pos2 += count; }         // PAF D = target only = raw I (:1427-1433)
+            else { /* other ops: the reference ends the run and moves nothing (:1358-1440) */
+                push(SR_OP_X, 0);
+                if (ops.size() > first && (ops.back() & 15u) == SR_OP_M) ops.push_back((0u << 4) | SR_OP_X);
+            }
+            count = 0;
+            if (pos1 > 0xffffffffULL || pos2 > 0xffffffffULL) { bad = true; break; }
+        }
+        if (bad) { rc_err = fail(SR_ERR_INVALID, "PAF CIGAR longer than 2^32 bases"); break; }
+        c->pair_q.push_back(q); c->pair_t.push_back(t); isrev.push_back(rc ? 1 : 0);
+        qs.push_back((uint32_t)qb); ts.push_back((uint32_t)tb);
+        c->cigar_base.push_back(ops.size());
+    }
+    fclose(f);
+    if (rc_err) return rc_err;
+    const uint32_t np = (uint32_t)c->pair_q.size();
+    std::vector<uint32_t> cnt(np ? np : 1, 0);
+    for (uint32_t i = 0; i < np; i++) cnt[i] = (uint32_t)(c->cigar_base[i + 1] - c->cigar_base[i]);
+    c->dp_cells = 0;
+    // ---- device buffers
+    int r;
+    void *d;
+    SrAlignArgs &a = c->aa;
+    memset(&a, 0, sizeof(a));
+#define DEV_UP(dst, T, hostvec)                                                               \
+    do {                                                                                      \
+        std::vector<T> tmp_ = (hostvec);                                                      \
+        if (tmp_.empty()) tmp_.push_back(T());                                                \
+        if ((r = dev_alloc(c, &d, tmp_.size() * sizeof(T)))) return r;                        \
+        HIPCHK(hipMemcpy(d, tmp_.data(), tmp_.size() * sizeof(T), hipMemcpyHostToDevice));    \
+        dst = (T *)d;                                                                         \
+    } while (0)
+    uint32_t *d_pq, *d_pt, *d_len, *d_ops, *d_cnt, *d_qs, *d_ts; uint64_t *d_goff, *d_cbase; uint8_t *d_rev; int32_t *d_score;
+    DEV_UP(d_pq, uint32_t, c->pair_q); DEV_UP(d_pt, uint32_t, c->pair_t); DEV_UP(d_len, uint32_t, c->len);
+    DEV_UP(d_goff, uint64_t, c->goff); DEV_UP(d_cbase, uint64_t, c->cigar_base); DEV_UP(d_ops, uint32_t, ops);
+    DEV_UP(d_cnt, uint32_t, cnt); DEV_UP(d_qs, uint32_t, qs); DEV_UP(d_ts, uint32_t, ts); DEV_UP(d_rev, uint8_t, isrev);
+    DEV_UP(d_score, int32_t, std::vector<int32_t>(np ? np : 1, 0));
+    DEV_UP(c->d_max_score, int32_t, std::vector<int32_t>(np ? np : 1, INT_MAX));   // no divergence filter on PAF input
+#undef DEV_UP
+    if ((r = dev_alloc(c, &d, sizeof(uint32_t)))) return r; c->d_queue = (uint32_t *)d;
+    if ((r = dev_alloc(c, &d, 16 * sizeof(unsigned long long)))) return r; c->d_counters = (unsigned long long *)d;
+    if ((r = dev_alloc(c, &d, sizeof(int)))) return r; c->d_error = (int *)d;
+    if ((r = dev_alloc(c, &d, c->uf_size * 8))) return r; c->d_nodes = (unsigned long long *)d;
+    if ((r = dev_alloc(c, &d, c->uf_size * 8))) return r; c->d_minarr = (unsigned long long *)d;
+    if ((r = dev_alloc(c, &d, c->uf_size * 8))) return r; c->d_labels = (unsigned long long *)d;
+    HIPCHK(hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream));
+    HIPCHK(hipMemsetAsync(c->d_error, 0, sizeof(int), c->stream));
+    a.npairs = 0; a.counters = c->d_counters; a.error_flag = c->d_error;
+    SrUniteArgs &u = c->ua;
+    memset(&u, 0, sizeof(u));
+    u.pair_q = d_pq; u.pair_t = d_pt; u.npairs = np; u.seqlen = d_len; u.seq_goff = d_goff;
+    u.q_start = d_qs; u.t_start = d_ts;
+    u.is_reverse = d_rev; u.score = d_score; u.max_score = c->d_max_score;
+    u.cigar_ops = d_ops; u.cigar_base = d_cbase; u.cigar_cnt = d_cnt;
+    u.min_match_len = p->min_match_len; u.nodes = c->d_nodes; u.uf_size = c->uf_size;
+    u.counters = c->d_counters; u.error_flag = c->d_error;
+    if (srk_uf_init(c->d_nodes, c->total_len, c->uf_size, c->stream)) return fail(SR_ERR_HIP, "uf init launch failed");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->loaded = true; c->from_paf = true;
+    return SR_OK;
+}
+
+extern "C" int sr_unite_paf(const sr_seqset *seqs, const sr_params *p, const char *paf_path, uint64_t *parent_out) {
+    if (!seqs || !p || !paf_path || !parent_out) return fail(SR_ERR_INVALID, "null argument");
+    sr_ctx *c = nullptr;
+    int r = sr_ctx_create(p->device, &c);
+    if (r) return r;
+    if (!(r = sr_ctx_load_paf(c, seqs, p, paf_path)) && !(r = sr_ctx_unite(c)) && !(r = sr_ctx_sync(c))) {
         if (p->canonical_labels) r = sr_ctx_download_labels(c, parent_out);
         else r = sr_ctx_download_uf(c, parent_out);
         if (!r) r = sr_ctx_sync(c);

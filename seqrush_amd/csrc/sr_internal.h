@@ -90,6 +90,7 @@ struct SrUniteArgs {
     uint32_t npairs;
     const uint32_t *seqlen;
     const uint64_t *seq_goff;       // [n] global offsets (concatenated coordinates)
+    const uint32_t *q_start, *t_start; // [npairs] first aligned position (alignment orientation) or NULL = 0 (PAF input)
     const uint8_t *is_reverse;
     const int32_t *score;
     const int32_t *max_score;       // [npairs] divergence filter bound or INT_MAX

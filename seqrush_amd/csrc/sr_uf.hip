@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(WG) sr_unite_kernel(SrUniteArgs a) {
         const unsigned long long qlen = a.seqlen[q];
         const bool rc = a.is_reverse[pair] != 0;
         const uint32_t *ops = a.cigar_ops + a.cigar_base[pair];
-        if (tid == 0) { carry_q = 0; carry_t = 0; }
+        if (tid == 0) { carry_q = a.q_start ? a.q_start[pair] : 0; carry_t = a.t_start ? a.t_start[pair] : 0; }
         __syncthreads();
         for (uint32_t base = 0; base < cnt; base += WG) {
             const uint32_t i = base + tid;

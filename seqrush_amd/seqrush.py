@@ -30,7 +30,7 @@ class Args:
     orientation_scores: str = "0,1,1,1"     # --orientation-scores
     max_divergence: Optional[float] = None  # -d
     sparsification: str = "none"            # -x
-    paf: Optional[str] = None               # -p (not implemented: seam 3 input)
+    paf: Optional[str] = None               # -p: replay alignments from a PAF file instead of aligning
     output_alignments: Optional[str] = None  # --output-alignments
     no_compact: bool = True                 # only --no-compact is implemented
     no_sort: bool = True                    # only --no-sort is implemented
@@ -241,6 +241,11 @@ class Context:
         self.seqset = seqset
         check(self.L.sr_ctx_load(self._h, C.byref(seqset.c), C.byref(params.c)))
 
+    def load_paf(self, seqset: SeqSet, params: Params, paf_path: str):
+        """`seqrush -p`: replay the records of a PAF file (then unite()); there is no alignment stage"""
+        self.seqset = seqset
+        check(self.L.sr_ctx_load_paf(self._h, C.byref(seqset.c), C.byref(params.c), paf_path.encode()))
+
     def reset_uf(self):
         check(self.L.sr_ctx_reset_uf(self._h))
 
@@ -358,8 +363,14 @@ class SeqRush:
 
     def align_and_unite(self, args: Args):
         """align_and_unite_with_allwave (src/seqrush.rs:611-757) on the device"""
-        if args.paf is not None:
-            raise SeqRushError(-6, "-p/--paf input is not implemented (SURVEY 8f rank 4)")
+        if args.paf is not None:                      # align_and_unite_from_paf (src/seqrush.rs:510-609)
+            print(f"Reading alignments from PAF file: {args.paf}")
+            self.ctx.load_paf(self.seqset, Params.from_args(args), args.paf)
+            self.ctx.unite()
+            self.ctx.sync()
+            self.labels = self.ctx.download_labels()
+            self.ctx.sync()
+            return
         if args.aligner.lower() != "allwave":
             raise SeqRushError(-6, f"aligner '{args.aligner}' is out of scope; only 'allwave'")
         params = Params.from_args(args)

@@ -201,6 +201,103 @@ def test_fused_entry_points_and_paf(gpu, tmp_path):
     assert np.array_equal(o2.canonical_labels(), labels)
 
 
+def oracle_paf_replay(recs, paf_text, k=0):
+    """align_and_unite_from_paf (src/seqrush.rs:510-609) on the oracle: same record rules"""
+    o = ob.OracleSeqRush(records=recs)
+    idx = {}
+    for i, (name, _) in enumerate(recs):
+        idx[name] = i                                   # HashMap collect: a later duplicate wins
+    for ln in paf_text.split("\n"):
+        if ln == "":
+            continue
+        f = ln.split("\t")
+        if len(f) < 12:
+            continue
+        cg = ""
+        for x in f[12:]:
+            if x.startswith("cg:Z:"):
+                cg = x[5:]
+                break
+        if f[0] not in idx or f[5] not in idx:
+            continue
+        assert o.process_alignment(cg, idx[f[0]], idx[f[5]], k, f[4] == "-", int(f[2]), int(f[3]),
+                                   int(f[7]), int(f[8])) >= 0
+    return o.canonical_labels()
+
+
+def gpu_paf_labels(recs, paf_path, **kw):
+    ss = SeqSet(recs)
+    ctx = Context(0)
+    ctx.load_paf(ss, Params(**kw), str(paf_path))
+    ctx.unite(); ctx.sync()
+    labels = ctx.download_labels()
+    ctx.sync()
+    assert ctx.align_kernel == ""
+    with pytest.raises(sa.SeqRushError):
+        ctx.alignments()
+    ctx.close()
+    return labels
+
+
+def test_paf_input_round_trip(gpu, tmp_path):
+    """`seqrush -p`: the PAF this library writes, replayed through sr_ctx_load_paf + sr_unite_kernel, gives the
+    partition of the direct path, and the oracle replaying the same file agrees (incl. RC queries, -k)"""
+    recs = synth.snp_family(5, 700, 0.05, 91, rc_every=2)
+    al_ss, al = sa.AllwaveAligner().align_raw([sa.AlignmentSequence(a, b) for a, b in recs])
+    paf = tmp_path / "rt.paf"
+    al.write_paf(al_ss, str(paf))
+    text = paf.read_text()
+    for k in (0, 15):
+        _, _, labels_direct, _, _ = run_gpu(recs, min_match_len=k)
+        labels_paf = gpu_paf_labels(recs, paf, min_match_len=k)
+        assert np.array_equal(labels_paf, labels_direct)
+        assert np.array_equal(labels_paf, oracle_paf_replay(recs, text, k))
+    # fused entry point
+    L = _lib.load()
+    ss = SeqSet(recs)
+    p = Params()
+    p.c.canonical_labels = 1
+    out = np.zeros(2 * ss.total_length + 2, dtype=np.uint64)
+    _lib.check(L.sr_unite_paf(C.byref(ss.c), C.byref(p.c), str(paf).encode(), out.ctypes.data_as(C.POINTER(C.c_uint64))))
+    assert np.array_equal(out, oracle_paf_replay(recs, text, 0))
+
+
+def test_paf_input_foreign_records(gpu, tmp_path):
+    """records as another aligner would write them: M ops with mismatches inside, partial alignments with
+    start offsets, strand '-' offsets in RC space, counts omitted, unknown names, short lines, no cg tag,
+    lower-case bases (process_alignment compares raw bytes, src/seqrush.rs:1162-1176, 1268-1330)"""
+    a = synth.to_bytes(synth.base_sequence(300, 301))
+    b = bytearray(a); b[40] = ord("A") if a[40] != ord("A") else ord("C"); b[41] = ord("G") if a[41] != ord("G") else ord("T")
+    b = bytes(b[:150] + b[160:])                        # 2 substitutions + a 10-base deletion
+    c = synth.reverse_complement(a)[20:260]
+    d = a[:100].lower() + a[100:]
+    recs = [("a", a), ("b", b), ("c", c), ("d", d), ("a", a[:50] + b"ACGT")]   # duplicate id: the later one wins
+    lines = [
+        "a\t300\t0\t300\t+\tb\t290\t0\t290\t280\t300\t60\tcg:Z:150M10I140M",          # query 'a' = LAST record named a
+        "b\t290\t10\t150\t+\td\t300\t10\t150\t138\t140\t60\tNM:i:2\tcg:Z:140M",
+        "c\t240\t0\t240\t-\td\t300\t40\t280\t240\t240\t60\tcg:Z:240=",
+        "c\t240\t5\t105\t-\td\t300\t45\t145\t100\t100\t60\tcg:Z:50=X49=",
+        "b\t290\t0\t290\t+\tb\t290\t0\t290\t290\t290\t60\tcg:Z:290=",
+        "d\t300\t0\t10\t+\tb\t290\t0\t12\t10\t12\t60\tcg:Z:5=D=I4=DD",
+        "zzz\t10\t0\t10\t+\tb\t290\t0\t10\t10\t10\t60\tcg:Z:10=",
+        "b\t290\t0\t10\t+\td\t300",
+        "b\t290\t0\t10\t+\td\t300\t0\t10\t10\t10\t60\ttp:A:P",
+        "",
+        "d\t300\t250\t300\t+\tb\t290\t280\t290\t10\t50\t60\tcg:Z:50M",               # runs past the target's end
+    ]
+    text = "\n".join(lines) + "\n"
+    paf = tmp_path / "foreign.paf"
+    paf.write_text(text)
+    for k in (0, 8):
+        assert np.array_equal(gpu_paf_labels(recs, paf, min_match_len=k), oracle_paf_replay(recs, text, k))
+    bad = tmp_path / "bad.paf"
+    bad.write_text("a\tx\t0\t3\t+\tb\t3\t0\t3\t3\t3\t60\tcg:Z:3=\n")
+    with pytest.raises(sa.SeqRushError):
+        gpu_paf_labels(recs, bad)
+    with pytest.raises(sa.SeqRushError):
+        gpu_paf_labels(recs, tmp_path / "missing.paf")
+
+
 def test_error_paths(gpu):
     with pytest.raises(sa.SeqRushError) as e:
         run_gpu([("a", b"ACGT"), ("b", b"")])
@@ -376,6 +473,18 @@ def test_cpp_cli_binary(gpu, tmp_path):
     assert canon_gfa(out.read_text()) == canon_gfa(o.gfa(canonical=True)[0])
     r = subprocess.run([exe, "-s", str(fa), "-o", str(out)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 1 and "only --no-sort --no-compact" in r.stderr
+    # --output-alignments then -p (both directions of seam 3): same graph from the replayed PAF, C++ and Python hosts
+    paf, out2, out3 = tmp_path / "o.paf", tmp_path / "o2.gfa", tmp_path / "o3.gfa"
+    r = subprocess.run([exe, "-s", str(fa), "-o", str(out), "--no-sort", "--no-compact", "--output-alignments", str(paf)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and len(paf.read_text().strip().split("\n")) == 25
+    r = subprocess.run([exe, "-s", str(fa), "-o", str(out2), "--no-sort", "--no-compact", "-p", str(paf)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "Reading alignments from PAF file" in r.stdout, r.stderr
+    assert canon_gfa(out2.read_text()) == canon_gfa(out.read_text())
+    from seqrush_amd.__main__ import main
+    assert main(["-s", str(fa), "-o", str(out3), "--no-sort", "--no-compact", "-p", str(paf)]) == 0
+    assert canon_gfa(out3.read_text()) == canon_gfa(out.read_text())
 
 
 def test_multi_rank_bench_matches_single_rank(gpu):
