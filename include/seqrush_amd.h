@@ -169,8 +169,13 @@ int sr_ctx_download_labels(sr_ctx *c, uint64_t *labels_out);
  * load + unite + download (raw uf_rush nodes, or canonical labels with p->canonical_labels). */
 int sr_ctx_load_paf(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const char *paf_path);
 int sr_unite_paf(const sr_seqset *seqs, const sr_params *p, const char *paf_path, uint64_t *parent_out);
+/* graph induction on the device from the context's union-find (node ids in first-
+ * encounter order, node bases, path steps, deduplicated edges; src/bidirected_builder.rs:17-289,
+ * src/bidirected_ops.rs:813-825) + GFA text formatted on the host.  Byte-identical to sr_build_gfa() on the
+ * canonical labels of the same context; *gfa is malloc'ed (sr_free). */
+int sr_ctx_build_gfa(sr_ctx *c, const sr_seqset *seqs, char **gfa, uint64_t *n_nodes, uint64_t *n_edges);
 /* timing of the last enqueued kernels, measured with hipEvents on the
- * context's stream: which = 0 align, 1 unite, 2 labels/merge */
+ * context's stream: which = 0 align, 1 unite, 2 labels/merge, 3 graph induction */
 int sr_ctx_kernel_ms(sr_ctx *c, int which, float *ms);
 /* name of the alignment kernel the loaded context launches ("sr_align_blk_kernel",
  * "sr_align_bfs_kernel" or "sr_align_kernel"), NULL before sr_ctx_load */

@@ -21,7 +21,7 @@ EXPORTS = [
     "sr_ctx_num_pairs", "sr_ctx_dp_cells", "sr_ctx_labels_device", "sr_ctx_merge_labels",
     "sr_ctx_download_labels", "sr_ctx_kernel_ms", "sr_ctx_counters", "sr_build_gfa", "sr_free",
     "sr_last_error", "sr_abi_version", "sr_device_count", "sr_pair_list", "sr_ctx_align_kernel",
-    "sr_ctx_load_paf", "sr_unite_paf",
+    "sr_ctx_load_paf", "sr_unite_paf", "sr_ctx_build_gfa",
 ]
 
 
@@ -105,6 +105,7 @@ def load():
     L.sr_ctx_align_kernel.argtypes = [vp]; L.sr_ctx_align_kernel.restype = C.c_char_p
     L.sr_ctx_load_paf.argtypes = [vp, PS, PP, C.c_char_p]
     L.sr_unite_paf.argtypes = [PS, PP, C.c_char_p, C.POINTER(u64)]
+    L.sr_ctx_build_gfa.argtypes = [vp, PS, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
     L.sr_ctx_counters.argtypes = [vp, C.POINTER(u64)]
     L.sr_build_gfa.argtypes = [PS, C.POINTER(u64), C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
     L.sr_pair_list.argtypes = [C.c_uint32, PP, C.POINTER(C.POINTER(C.c_uint32)),

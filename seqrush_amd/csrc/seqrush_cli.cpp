@@ -96,21 +96,28 @@ int main(int argc, char **argv) {
     p.min_match_len = (uint64_t)k; p.max_divergence = max_div; p.device = device; p.canonical_labels = 1;
     printf("Building graph with %zu sequences (total length: %zu)\n", seqs.size(), bases.size());
     printf("Total sequence pairs: %zu (sparsification: %s)\n", seqs.size() * seqs.size(), sparsify.c_str());
-    if (!paf_out.empty() && paf_in.empty()) {
-        sr_alignments *al = nullptr;
-        if (sr_align_all(&set, &p, &al)) { fprintf(stderr, "Error: %s\n", sr_last_error()); return 1; }
-        printf("Writing alignments to %s\n", paf_out.c_str());
-        if (sr_write_paf(al, &set, paf_out.c_str())) { fprintf(stderr, "Error: %s\n", sr_last_error()); return 1; }
-        sr_alignments_free(al);
-    }
-    std::vector<uint64_t> labels(2 * bases.size() + 2);
+    // one resident context: load (or PAF replay) -> align -> unite -> graph induction, all on the device
+    sr_ctx *ctx = nullptr;
+    auto die = [&]() { fprintf(stderr, "Error: %s\n", sr_last_error()); if (ctx) sr_ctx_destroy(ctx); return 1; };
+    if (sr_ctx_create(device, &ctx)) return die();
     if (!paf_in.empty()) {                                   // align_and_unite_from_paf (src/seqrush.rs:510-609)
         printf("Reading alignments from PAF file: %s\n", paf_in.c_str());
-        if (sr_unite_paf(&set, &p, paf_in.c_str(), labels.data())) { fprintf(stderr, "Error: %s\n", sr_last_error()); return 1; }
-    } else if (sr_align_and_unite(&set, &p, labels.data())) { fprintf(stderr, "Error: %s\n", sr_last_error()); return 1; }
+        if (sr_ctx_load_paf(ctx, &set, &p, paf_in.c_str())) return die();
+    } else {
+        if (sr_ctx_load(ctx, &set, &p) || sr_ctx_align(ctx)) return die();
+        if (!paf_out.empty()) {                              // --output-alignments (src/seqrush.rs:678-716)
+            sr_alignments *al = nullptr;
+            if (sr_ctx_alignments(ctx, &al)) return die();
+            printf("Writing alignments to %s\n", paf_out.c_str());
+            if (sr_write_paf(al, &set, paf_out.c_str())) { sr_alignments_free(al); return die(); }
+            sr_alignments_free(al);
+        }
+    }
+    if (sr_ctx_unite(ctx) || sr_ctx_sync(ctx)) return die();
     char *gfa = nullptr;
     uint64_t nn = 0, ne = 0;
-    if (sr_build_gfa(&set, labels.data(), &gfa, &nn, &ne)) { fprintf(stderr, "Error: %s\n", sr_last_error()); return 1; }
+    if (sr_ctx_build_gfa(ctx, &set, &gfa, &nn, &ne)) return die();
+    sr_ctx_destroy(ctx);
     std::ofstream o(output, std::ios::binary);
     o << gfa;
     sr_free(gfa);

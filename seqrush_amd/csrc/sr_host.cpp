@@ -168,8 +168,8 @@ struct sr_ctx {
     int *d_error = nullptr;
     uint32_t *d_queue = nullptr;
     int32_t *d_max_score = nullptr;
-    hipEvent_t ev[3][2]{};
-    bool ev_valid[3] = {false, false, false};
+    hipEvent_t ev[4][2]{};
+    bool ev_valid[4] = {false, false, false, false};
     bool loaded = false;
     bool from_paf = false;             // loaded by sr_ctx_load_paf: no alignment stage, no sr_alignments
 };
@@ -197,7 +197,7 @@ extern "C" int sr_ctx_create(int device, sr_ctx **out) {
     c->device = device;
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return fail(SR_ERR_HIP, "hipStreamCreate failed"); }
     c->own_stream = true;
-    for (int i = 0; i < 3; i++)
+    for (int i = 0; i < 4; i++)
         for (int j = 0; j < 2; j++)
             if (hipEventCreate(&c->ev[i][j]) != hipSuccess) { delete c; return fail(SR_ERR_HIP, "hipEventCreate failed"); }
     *out = c;
@@ -209,7 +209,7 @@ extern "C" void sr_ctx_destroy(sr_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     free_dev(c);
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 2; j++) if (c->ev[i][j]) (void)hipEventDestroy(c->ev[i][j]);
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 2; j++) if (c->ev[i][j]) (void)hipEventDestroy(c->ev[i][j]);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -557,7 +557,7 @@ extern "C" const char *sr_ctx_align_kernel(const sr_ctx *c) {
 }
 
 extern "C" int sr_ctx_kernel_ms(sr_ctx *c, int which, float *ms) {
-    if (!c || which < 0 || which > 2 || !c->ev_valid[which]) return fail(SR_ERR_INVALID, "no timing recorded");
+    if (!c || which < 0 || which > 3 || !c->ev_valid[which]) return fail(SR_ERR_INVALID, "no timing recorded");
     HIPCHK(hipEventSynchronize(c->ev[which][1]));
     HIPCHK(hipEventElapsedTime(ms, c->ev[which][0], c->ev[which][1]));
     return SR_OK;
@@ -885,6 +885,7 @@ extern "C" int sr_unite_paf(const sr_seqset *seqs, const sr_params *p, const cha
     return r;
 }
 
+
 // UFRush::find (read-only walk) / same, uf_rush lib.rs:112-133, 72-84
 extern "C" uint64_t sr_uf_find(const uint64_t *nodes, uint64_t n, uint64_t x) {
     const uint64_t mask = 0x03FFFFFFFFFFFFFFULL;
@@ -941,6 +942,41 @@ struct PairHash {
     }
 };
 
+// write_gfa layout (src/bidirected_ops.rs:880-925) from compact arrays: node_base[id-1], step(g) = id<<1|rev,
+// edge(i) = (from, to) handles in first-seen order
+template <typename StepFn, typename EdgeFn>
+static char *format_gfa(const sr_seqset *seqs, uint64_t n_nodes, const uint8_t *node_base, StepFn step, uint64_t n_edges,
+                        EdgeFn edge) {
+    const uint64_t N = seqs->offsets[seqs->n];
+    std::string out;
+    out.reserve(N * 8 + 64);
+    out += "H\tVN:Z:1.0\n";
+    char tmp[96];
+    for (uint64_t id = 1; id <= n_nodes; id++) {
+        snprintf(tmp, sizeof(tmp), "S\t%llu\t%c\n", (unsigned long long)id, (char)node_base[id - 1]);
+        out += tmp;
+    }
+    for (uint64_t i = 0; i < n_edges; i++) {
+        const std::pair<uint64_t, uint64_t> e = edge(i);
+        snprintf(tmp, sizeof(tmp), "L\t%llu\t%c\t%llu\t%c\t0M\n", (unsigned long long)(e.first >> 1),
+                 (e.first & 1) ? '-' : '+', (unsigned long long)(e.second >> 1), (e.second & 1) ? '-' : '+');
+        out += tmp;
+    }
+    for (uint32_t s = 0; s < seqs->n; s++) {
+        out += "P\t"; out += seqs->names[s]; out += "\t";
+        for (uint64_t g = seqs->offsets[s]; g < seqs->offsets[s + 1]; g++) {
+            if (g != seqs->offsets[s]) out += ',';
+            const uint64_t st = step(g);
+            snprintf(tmp, sizeof(tmp), "%llu%c", (unsigned long long)(st >> 1), (st & 1) ? '-' : '+');
+            out += tmp;
+        }
+        out += "\t*\n";
+    }
+    char *res = (char *)malloc(out.size() + 1);
+    memcpy(res, out.c_str(), out.size() + 1);
+    return res;
+}
+
 extern "C" int sr_build_gfa(const sr_seqset *seqs, const uint64_t *labels, char **gfa,
                             uint64_t *n_nodes, uint64_t *n_edges) {
     if (!seqs || !labels || !gfa || !seqs->names) return fail(SR_ERR_INVALID, "null argument");
@@ -978,32 +1014,60 @@ extern "C" int sr_build_gfa(const sr_seqset *seqs, const uint64_t *labels, char 
             eset.insert({from, to});
             eorder.push_back({from, to});
         }
-    std::string out;
-    out.reserve(N * 8 + 64);
-    out += "H\tVN:Z:1.0\n";
-    char tmp[96];
-    for (uint64_t id = 1; id < next_id; id++) {
-        snprintf(tmp, sizeof(tmp), "S\t%llu\t%c\n", (unsigned long long)id, (char)node_base[id]);
-        out += tmp;
-    }
-    for (auto &e : eorder) {
-        snprintf(tmp, sizeof(tmp), "L\t%llu\t%c\t%llu\t%c\t0M\n", (unsigned long long)(e.first >> 1),
-                 (e.first & 1) ? '-' : '+', (unsigned long long)(e.second >> 1), (e.second & 1) ? '-' : '+');
-        out += tmp;
-    }
-    for (uint32_t s = 0; s < seqs->n; s++) {
-        out += "P\t"; out += seqs->names[s]; out += "\t";
-        for (uint64_t g = seqs->offsets[s]; g < seqs->offsets[s + 1]; g++) {
-            if (g != seqs->offsets[s]) out += ',';
-            snprintf(tmp, sizeof(tmp), "%llu%c", (unsigned long long)(steps[g] >> 1), (steps[g] & 1) ? '-' : '+');
-            out += tmp;
-        }
-        out += "\t*\n";
-    }
-    char *res = (char *)malloc(out.size() + 1);
-    memcpy(res, out.c_str(), out.size() + 1);
-    *gfa = res;
+    *gfa = format_gfa(seqs, next_id - 1, node_base.data() + 1, [&](uint64_t g) { return steps[g]; }, eorder.size(),
+                      [&](uint64_t i) { return eorder[i]; });
     if (n_nodes) *n_nodes = next_id - 1;
     if (n_edges) *n_edges = eorder.size();
     return SR_OK;
 }
+
+// graph induction on the device from the context's union-find (sr_graph.hip); same
+// text as sr_build_gfa() on the downloaded canonical labels.  which = 3 of sr_ctx_kernel_ms times it.
+extern "C" int sr_ctx_build_gfa(sr_ctx *c, const sr_seqset *seqs, char **gfa, uint64_t *n_nodes, uint64_t *n_edges) {
+    if (!c || !c->loaded) return fail(SR_ERR_INVALID, "context not loaded");
+    if (!seqs || !gfa || !seqs->names) return fail(SR_ERR_INVALID, "null argument");
+    const uint64_t N = seqs->offsets[seqs->n];
+    if (seqs->n != c->n || N != c->total_len) return fail(SR_ERR_INVALID, "sequence set differs from the loaded one");
+    if (N >= 0x7fffffffULL) return fail(SR_ERR_UNSUPPORTED, "graph induction on device supports < 2^31 bases");
+    HIPCHK(hipSetDevice(c->device));
+    int r = sr_ctx_labels_device(c, (uint64_t *)c->d_labels);
+    if (r) return r;
+    std::vector<uint8_t> islast(N, 0);
+    for (uint32_t s = 0; s < seqs->n; s++) islast[seqs->offsets[s + 1] - 1] = 1;
+    uint64_t hcap = 64;
+    while (hcap < 2 * N + 16) hcap <<= 1;
+    const uint64_t ntiles = (N + 1023) / 1024 + 1;
+    struct Tmp { std::vector<void *> v; ~Tmp() { for (void *p : v) (void)hipFree(p); } } tmp;
+    auto dalloc = [&](size_t bytes) -> void * { void *p = nullptr; if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr; tmp.v.push_back(p); return p; };
+    uint8_t *d_bases = (uint8_t *)dalloc(N), *d_islast = (uint8_t *)dalloc(N), *d_nbase = (uint8_t *)dalloc(N);
+    uint32_t *d_flag = (uint32_t *)dalloc(N * 4), *d_nid = (uint32_t *)dalloc(N * 4), *d_steps = (uint32_t *)dalloc((N + 1) * 4);
+    uint32_t *d_eslot = (uint32_t *)dalloc(N * 4), *d_hvals = (uint32_t *)dalloc(hcap * 4), *d_tiles = (uint32_t *)dalloc(ntiles * 4);
+    uint32_t *d_counts = (uint32_t *)dalloc(8);
+    unsigned long long *d_hkeys = (unsigned long long *)dalloc(hcap * 8), *d_edges = (unsigned long long *)dalloc(N * 8);
+    if (!d_bases || !d_islast || !d_nbase || !d_flag || !d_nid || !d_steps || !d_eslot || !d_hvals || !d_tiles || !d_counts ||
+        !d_hkeys || !d_edges) return fail(SR_ERR_NOMEM, "not enough device memory for graph induction");
+    HIPCHK(hipMemcpyAsync(d_bases, seqs->bases, N, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d_islast, islast.data(), N, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipEventRecord(c->ev[3][0], c->stream));
+    // d_minarr (uf_size entries) is free again once the labels exist: first-position table
+    if (srk_graph_induce(c->d_labels, d_bases, d_islast, N, c->uf_size, c->d_minarr, d_flag, d_nid, d_steps, d_nbase, d_hkeys,
+                         d_hvals, hcap, d_eslot, d_edges, d_tiles, d_counts, c->d_error, c->stream))
+        return fail(SR_ERR_HIP, "graph induction launch failed");
+    HIPCHK(hipEventRecord(c->ev[3][1], c->stream));
+    c->ev_valid[3] = true;
+    if ((r = sr_ctx_sync(c))) return r;
+    uint32_t counts[2] = {0, 0};
+    HIPCHK(hipMemcpy(counts, d_counts, 8, hipMemcpyDeviceToHost));
+    std::vector<uint8_t> nbase(counts[0] ? counts[0] : 1);
+    std::vector<uint32_t> steps(N);
+    std::vector<unsigned long long> edges(counts[1] ? counts[1] : 1);
+    HIPCHK(hipMemcpy(nbase.data(), d_nbase, counts[0], hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(steps.data(), d_steps, N * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(edges.data(), d_edges, (size_t)counts[1] * 8, hipMemcpyDeviceToHost));
+    *gfa = format_gfa(seqs, counts[0], nbase.data(), [&](uint64_t g) { return (uint64_t)steps[g]; }, counts[1],
+                      [&](uint64_t i) { return std::pair<uint64_t, uint64_t>(edges[i] >> 32, edges[i] & 0xffffffffULL); });
+    if (n_nodes) *n_nodes = counts[0];
+    if (n_edges) *n_edges = counts[1];
+    return SR_OK;
+}
+

@@ -25,7 +25,8 @@ enum {
     SR_DEV_ERR_STACK = 8,         // biWFA recursion stack overflow
     SR_DEV_ERR_CIGAR_OVERFLOW = 16,
     SR_DEV_ERR_UF_SPIN = 32,      // union-find retry bound hit
-    SR_DEV_ERR_BREAKPOINT = 64    // breakpoint outside the segment
+    SR_DEV_ERR_BREAKPOINT = 64,   // breakpoint outside the segment
+    SR_DEV_ERR_GRAPH = 128        // graph induction: strands of a base in different components / hash table full
 };
 
 struct SrPen {
@@ -116,6 +117,11 @@ int srk_labels(unsigned long long *nodes, uint64_t uf_size, unsigned long long *
 int srk_merge(unsigned long long *nodes, uint64_t uf_size, const unsigned long long *labels,
               uint32_t count, int *error_flag, void *stream);
 int srk_align_max_lds(void);
+int srk_graph_induce(const unsigned long long *labels, const uint8_t *bases, const uint8_t *islast,
+                     uint64_t N, uint64_t uf_size, unsigned long long *first, uint32_t *flag, uint32_t *nid,
+                     uint32_t *steps, uint8_t *node_base, unsigned long long *hkeys, uint32_t *hvals,
+                     uint64_t hcap, uint32_t *eslot, unsigned long long *edges, uint32_t *tile_sum,
+                     uint32_t *counts, int *error_flag, void *stream);
 int srk_align_blk_supports(const SrPen *pen, const SrPen *ori);   // levels per block, 0 = no blocked instance
 #ifdef __cplusplus
 }

@@ -246,6 +246,15 @@ class Context:
         self.seqset = seqset
         check(self.L.sr_ctx_load_paf(self._h, C.byref(seqset.c), C.byref(params.c), paf_path.encode()))
 
+    def build_gfa(self):
+        """graph induction on the device from this context's union-find (SURVEY 8f rank 1) + GFA text;
+        -> (gfa_text, n_nodes, n_edges), byte-identical to build_gfa(seqset, download_labels())"""
+        out = C.c_void_p(); nn = C.c_uint64(); ne = C.c_uint64()
+        check(self.L.sr_ctx_build_gfa(self._h, C.byref(self.seqset.c), C.byref(out), C.byref(nn), C.byref(ne)))
+        text = C.cast(out, C.c_char_p).value.decode()
+        self.L.sr_free(out)
+        return text, int(nn.value), int(ne.value)
+
     def reset_uf(self):
         check(self.L.sr_ctx_reset_uf(self._h))
 
@@ -398,7 +407,7 @@ class SeqRush:
         if not (args.no_sort and args.no_compact):
             raise SeqRushError(-6, "only --no-sort --no-compact output is implemented "
                                    "(compaction / Ygs sort are outside the hot path)")
-        text, _, _ = build_gfa(self.seqset, self.labels)
+        text, _, _ = self.ctx.build_gfa()            # graph induction on the device
         with open(args.output, "w") as fh:
             fh.write(text)
 

@@ -298,6 +298,32 @@ def test_paf_input_foreign_records(gpu, tmp_path):
         gpu_paf_labels(recs, tmp_path / "missing.paf")
 
 
+@pytest.mark.parametrize("name", ["snp_rc", "indel", "c1", "paf_foreign"])
+def test_graph_induction_on_device(gpu, name, tmp_path):
+    """node ids / bases / path steps / deduplicated edges computed on the device from the
+    union-find give byte-identical GFA text to the host induction on the downloaded labels and (canonically)
+    to the oracle's graph (src/bidirected_builder.rs:17-289)"""
+    recs = {"snp_rc": lambda: synth.snp_family(6, 800, 0.05, 171, rc_every=2),
+            "indel": lambda: synth.indel_family(5, 1200, 0.04, 0.02, 172),
+            "c1": synth.config_c1,
+            "paf_foreign": lambda: [("x", b"ACGTTGCAACGT"), ("y", b"ACGTTGCAACGT"), ("z", b"ACGTTGCAACGTACGTTGCAACGT")]}[name]()
+    ss = SeqSet(recs)
+    ctx = Context(0)
+    ctx.load(ss, Params())
+    ctx.align(); ctx.unite(); ctx.sync()
+    dev_text, nn, ne = ctx.build_gfa()
+    assert ctx.kernel_ms(3) > 0
+    labels = ctx.download_labels()
+    ctx.sync()
+    host_text, hn, he = build_gfa(ss, labels)
+    ctx.close()
+    assert (nn, ne) == (hn, he)
+    assert dev_text == host_text                       # same node numbering, same L order, same P lines
+    o = ob.OracleSeqRush(records=recs)
+    o.align_and_unite(ob.default_params())
+    assert canon_gfa(dev_text) == canon_gfa(o.gfa(canonical=True)[0])
+
+
 def test_error_paths(gpu):
     with pytest.raises(sa.SeqRushError) as e:
         run_gpu([("a", b"ACGT"), ("b", b"")])
