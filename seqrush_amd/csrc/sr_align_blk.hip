@@ -1,6 +1,9 @@
 // sr_align_blk.hip -- translation unit of the score-blocked, wave-tiled biWFA kernel (see sr_align_blk.inc)
 #include "sr_dev_common.h"
 #define SR_BLK_TU 1
+// 16 segments (32 aligners) per pass keep the static LDS of a workgroup below 16 KB: 8 workgroups per CU
+#undef SR_BFS_MAXACT
+#define SR_BFS_MAXACT 16
 #include "sr_align_bfs.inc"
 #ifndef SR_BLK_MIN_WAVES
 #define SR_BLK_MIN_WAVES 4

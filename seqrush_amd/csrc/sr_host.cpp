@@ -385,7 +385,7 @@ extern "C" int sr_ctx_load(sr_ctx *c, const sr_seqset *seqs, const sr_params *p)
     if (const char *e = getenv("SR_WG_PER_CU")) wg_per_cu = std::max(1, atoi(e));
     c->nthreads = impl ? 256 : 128;
     if (const char *e = getenv("SR_ALIGN_THREADS")) { int v = atoi(e); if (impl ? (v == 128 || v == 256 || v == 512) : (v == 64 || v == 128 || v == 256)) c->nthreads = v; }
-    const size_t lds_per_wg = c->lds_bytes + (impl == 2 ? 27 : impl ? 28 : 8) * 1024;
+    const size_t lds_per_wg = c->lds_bytes + (impl == 2 ? 16 : impl ? 28 : 8) * 1024;
     wg_per_cu = (int)std::min<size_t>((size_t)wg_per_cu, std::max<size_t>(1, (160 * 1024) / lds_per_wg));
     const int ring_scope = std::max(pen.scope, ori.scope);
     const int ring_cap = (int)((2 * maxlen + 3 + 7) & ~7ULL);
@@ -455,6 +455,7 @@ extern "C" int sr_ctx_load(sr_ctx *c, const sr_seqset *seqs, const sr_params *p)
         if ((r = dev_alloc(c, &d, (uint64_t)nwg * bseg_wg))) return r; a.bseg = (int *)d;
         if ((r = dev_alloc(c, &d, (uint64_t)nwg * bbt_wg))) return r; a.bbt = (uint32_t *)d;
         if (bcl_wg) { if ((r = dev_alloc(c, &d, (uint64_t)nwg * bcl_wg * 4))) return r; a.bcl = (uint32_t *)d; a.bcl_wg_stride = bcl_wg; }
+        if (impl == 2) { if ((r = dev_alloc(c, &d, (uint64_t)nwg * 32 * 32 * 4))) return r; a.bmak = (int *)d; }
     } else {
         if ((r = dev_alloc(c, &d, (uint64_t)nwg * ring_wg * osz))) return r; a.ring = d;
         if ((r = dev_alloc(c, &d, (uint64_t)nwg * hist_wg * osz))) return r; a.hist = d;

@@ -75,6 +75,7 @@ struct SrAlignArgs {
     uint32_t *bbt;             // [bbase_jobs][SR_BFS_BTCAP] reversed run-length ops of finished base cases
     uint32_t *bcl;             // impl 2: breakpoint candidate list, bcl_wg_stride entries per workgroup
     uint64_t bcl_wg_stride;
+    int *bmak;                 // impl 2: per workgroup [32 aligners][32 ring levels] max M antidiagonal (breakpoint pruning)
     // outputs
     uint8_t *is_reverse;       // [npairs]
     int32_t *score;            // [npairs]
