@@ -100,6 +100,15 @@ template <typename OT>
 __device__ __forceinline__ void st4(GP<OT> row, unsigned idx0, V4<OT> v) {
     *(V4<OT> __attribute__((address_space(1))) *)(row + idx0) = v;
 }
+// streaming variants: rows that are (almost) never read again should not displace the rows that are
+template <typename OT>
+__device__ __forceinline__ void st4_nt(GP<OT> row, unsigned idx0, V4<OT> v) {
+    __builtin_nontemporal_store(v, (V4<OT> __attribute__((address_space(1))) *)(row + idx0));
+}
+template <typename OT>
+__device__ __forceinline__ V4<OT> ld4_nt(GP<OT> row, unsigned idx0) {
+    return __builtin_nontemporal_load((const V4<OT> __attribute__((address_space(1))) *)(row + idx0));
+}
 
 // ---------------------------------------------------------------- CIGAR out
 __device__ __forceinline__ void cig_append(GP<uint32_t> ops, uint32_t &cnt, uint32_t cap, int op,
