@@ -148,6 +148,16 @@ def test_50kb_pair_int32_offsets(gpu):
     check_parity(recs)
 
 
+@pytest.mark.parametrize("length", [32000, 32001])
+def test_offset_width_boundary(gpu, length):
+    """longest sequence 32000 -> int16 rows, 32001 -> int32 rows (same kernel template, other instantiation);
+    both sides of the switch match the oracle, including a shorter partner and a reverse-complemented one"""
+    a = synth.to_bytes(synth.substitute(synth.base_sequence(length, 71), 0.004, 72))
+    b = synth.to_bytes(synth.substitute(synth.base_sequence(length, 71), 0.004, 73))[: length - 300]
+    c = synth.reverse_complement(synth.to_bytes(synth.substitute(synth.base_sequence(length, 71), 0.004, 74))[200:])
+    check_parity([("a", a), ("b", b), ("c", c)])
+
+
 def test_aligner_trait_records(gpu):
     """Seam 1: create_aligner('allwave').align_sequences -> AlignmentRecord list (src/aligner.rs:27-33)"""
     recs = synth.snp_family(3, 300, 0.05, 71, rc_every=3)
@@ -388,6 +398,10 @@ def test_full_size_c2_properties(gpu):
     lab_base = bases[(labels[: 2 * len(bases)] >> np.uint64(1)).astype(np.int64)]
     assert np.array_equal(lab_base[0::2], bases) and np.array_equal(lab_base[1::2], bases)
     gfa, nn, ne = build_gfa(ss, labels)
+    # graph induction on the device at full size (320 kb: 313 scan tiles, 1 M-slot edge table) == host induction
+    ctx = Context(0); ctx.load(ss, Params()); ctx.align(); ctx.unite(); ctx.sync()
+    dev_gfa, dn, de = ctx.build_gfa(); ctx.close()
+    assert (dn, de) == (nn, ne) and dev_gfa == gfa
     seg = {}
     for l in gfa.split("\n"):
         if l.startswith("S\t"):
