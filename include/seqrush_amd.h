@@ -175,15 +175,17 @@ int sr_unite_paf(const sr_seqset *seqs, const sr_params *p, const char *paf_path
  * canonical labels of the same context; *gfa is malloc'ed (sr_free). */
 int sr_ctx_build_gfa(sr_ctx *c, const sr_seqset *seqs, char **gfa, uint64_t *n_nodes, uint64_t *n_edges);
 /* timing of the last enqueued kernels, measured with hipEvents on the
- * context's stream: which = 0 align, 1 unite, 2 labels/merge, 3 graph induction */
+ * context's stream: which = 0 align (the alignment kernel proper), 1 unite, 2 labels/merge, 3 graph induction,
+ * 4 the orientation kernel (when orientation runs as its own kernel before the alignment kernel) */
 int sr_ctx_kernel_ms(sr_ctx *c, int which, float *ms);
 /* name of the alignment kernel the loaded context launches ("sr_align_blk_kernel",
  * "sr_align_bfs_kernel" or "sr_align_kernel"), NULL before sr_ctx_load */
 const char *sr_ctx_align_kernel(const sr_ctx *c);
 /* device counters accumulated by the last align: [0] wavefront cells,
  * [1] wavefront steps, [2] base-case segments, [3] breakpoint searches,
- * [4] united bases (after unite), [5] match runs, [6..8] 100 MHz ticks summed
- * over workgroups: orientation, breakpoint search, base cases; [9] breakpoint-
+ * [4] united bases (after unite), [5] match runs, [6] orientation: wavefront cells of the orientation kernel (or,
+ * when orientation runs inside the alignment kernel, its 100 MHz ticks), [7..8] 100 MHz ticks summed
+ * over workgroups: breakpoint search, base cases; [9] breakpoint-
  * search passes; [10] ticks of whole pairs; [11..15] ticks inside the breakpoint
  * search: wavefront pass, barrier wait, phase-1 control, breakpoint detection, tail */
 int sr_ctx_counters(sr_ctx *c, uint64_t out[16]);

@@ -166,10 +166,12 @@ struct sr_ctx {
     unsigned long long *d_nodes = nullptr, *d_minarr = nullptr, *d_labels = nullptr;
     unsigned long long *d_counters = nullptr;
     int *d_error = nullptr;
-    uint32_t *d_queue = nullptr;
+    uint32_t *d_queue = nullptr, *d_oqueue = nullptr;
+    int onwg = 0;                      // workgroups (= waves) of the orientation kernel, 0 = orientation inside the alignment kernel
+    size_t olds_bytes = 0;
     int32_t *d_max_score = nullptr;
-    hipEvent_t ev[4][2]{};
-    bool ev_valid[4] = {false, false, false, false};
+    hipEvent_t ev[5][2]{};
+    bool ev_valid[5] = {false, false, false, false, false};
     bool loaded = false;
     bool from_paf = false;             // loaded by sr_ctx_load_paf: no alignment stage, no sr_alignments
 };
@@ -183,7 +185,7 @@ static void free_dev(sr_ctx *c) {
     for (void *p : c->dev_allocs) (void)hipFree(p);
     c->dev_allocs.clear();
     c->d_nodes = c->d_minarr = c->d_labels = c->d_counters = nullptr;
-    c->d_error = nullptr; c->d_queue = nullptr; c->d_max_score = nullptr;
+    c->d_error = nullptr; c->d_queue = nullptr; c->d_oqueue = nullptr; c->d_max_score = nullptr; c->onwg = 0;
     c->loaded = false; c->from_paf = false;
 }
 
@@ -197,7 +199,7 @@ extern "C" int sr_ctx_create(int device, sr_ctx **out) {
     c->device = device;
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return fail(SR_ERR_HIP, "hipStreamCreate failed"); }
     c->own_stream = true;
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 5; i++)
         for (int j = 0; j < 2; j++)
             if (hipEventCreate(&c->ev[i][j]) != hipSuccess) { delete c; return fail(SR_ERR_HIP, "hipEventCreate failed"); }
     *out = c;
@@ -209,7 +211,7 @@ extern "C" void sr_ctx_destroy(sr_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     free_dev(c);
-    for (int i = 0; i < 4; i++) for (int j = 0; j < 2; j++) if (c->ev[i][j]) (void)hipEventDestroy(c->ev[i][j]);
+    for (int i = 0; i < 5; i++) for (int j = 0; j < 2; j++) if (c->ev[i][j]) (void)hipEventDestroy(c->ev[i][j]);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -459,6 +461,20 @@ extern "C" int sr_ctx_load(sr_ctx *c, const sr_seqset *seqs, const sr_params *p)
         if ((r = dev_alloc(c, &d, (uint64_t)nwg * bbt_wg))) return r; a.bbt = (uint32_t *)d;
         if (bcl_wg) { if ((r = dev_alloc(c, &d, (uint64_t)nwg * bcl_wg * 4))) return r; a.bcl = (uint32_t *)d; a.bcl_wg_stride = bcl_wg; }
         if (impl == 2) { if ((r = dev_alloc(c, &d, (uint64_t)nwg * 32 * 32 * 4))) return r; a.bmak = (int *)d; }
+        // orientation as its own kernel, one pair per wave (sr_orient.hip); SR_PREORIENT=0 keeps it in the alignment kernel
+        const char *po = getenv("SR_PREORIENT");
+        if (impl == 2 && !(po && atoi(po) == 0) && (size_t)max_words * 12 <= 60 * 1024) {
+            const int orow = (int)((2 * ((2 * maxlen + 32) & ~3ULL) + 512 + 7) & ~7ULL);
+            const uint64_t oring_wg = ((uint64_t)(ori.scope + 1) * 3 + 1) * (uint64_t)orow + 256;
+            int onwg = (int)std::min<uint64_t>(np, (uint64_t)cus * 16);
+            while (onwg > 1 && (uint64_t)onwg * oring_wg * osz > (uint64_t)(free_b * 0.2)) onwg--;
+            if (onwg >= 1 && np > 0) {
+                if ((r = dev_alloc(c, &d, (uint64_t)onwg * oring_wg * osz))) return r; a.oring = d;
+                if ((r = dev_alloc(c, &d, sizeof(uint32_t)))) return r; c->d_oqueue = (uint32_t *)d;
+                a.oring_wg_stride = oring_wg; a.orow = orow; a.oqueue = c->d_oqueue; a.pre_oriented = 1;
+                c->onwg = onwg; c->olds_bytes = (size_t)max_words * 3 * 4;
+            }
+        }
     } else {
         if ((r = dev_alloc(c, &d, (uint64_t)nwg * ring_wg * osz))) return r; a.ring = d;
         if ((r = dev_alloc(c, &d, (uint64_t)nwg * hist_wg * osz))) return r; a.hist = d;
@@ -511,6 +527,14 @@ extern "C" int sr_ctx_align(sr_ctx *c) {
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemsetAsync(c->d_queue, 0, sizeof(uint32_t), c->stream));
     HIPCHK(hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream));
+    if (c->onwg > 0 && c->aa.npairs > 0) {           // which = 4: the orientation kernel
+        HIPCHK(hipMemsetAsync(c->d_oqueue, 0, sizeof(uint32_t), c->stream));
+        HIPCHK(hipEventRecord(c->ev[4][0], c->stream));
+        int r = srk_orient(&c->aa, c->onwg, c->olds_bytes, c->off16, c->stream);
+        if (r) return fail(SR_ERR_HIP, std::string("orientation kernel launch failed: ") + hipGetErrorString((hipError_t)r));
+        HIPCHK(hipEventRecord(c->ev[4][1], c->stream));
+        c->ev_valid[4] = true;
+    }
     HIPCHK(hipEventRecord(c->ev[0][0], c->stream));
     if (c->aa.npairs > 0) {
         int r = srk_align(&c->aa, c->nwg, c->lds_bytes, c->off16, c->nthreads, c->stream);
@@ -561,7 +585,7 @@ extern "C" const char *sr_ctx_align_kernel(const sr_ctx *c) {
 }
 
 extern "C" int sr_ctx_kernel_ms(sr_ctx *c, int which, float *ms) {
-    if (!c || which < 0 || which > 3 || !c->ev_valid[which]) return fail(SR_ERR_INVALID, "no timing recorded");
+    if (!c || which < 0 || which > 4 || !c->ev_valid[which]) return fail(SR_ERR_INVALID, "no timing recorded");
     HIPCHK(hipEventSynchronize(c->ev[which][1]));
     HIPCHK(hipEventElapsedTime(ms, c->ev[which][0], c->ev[which][1]));
     return SR_OK;

@@ -75,6 +75,12 @@ struct SrAlignArgs {
     uint32_t *bbt;             // [bbase_jobs][SR_BFS_BTCAP] reversed run-length ops of finished base cases
     uint32_t *bcl;             // impl 2: breakpoint candidate list, bcl_wg_stride entries per workgroup
     uint64_t bcl_wg_stride;
+    // orientation as its own kernel (sr_orient.hip): one pair per wave
+    void *oring;               // per 64-thread workgroup: [ori.scope+1 levels][M,I1,D1] rows of orow offsets + NULL row
+    uint64_t oring_wg_stride;
+    int orow;
+    uint32_t *oqueue;          // pair queue of the orientation kernel
+    int pre_oriented;          // 1: is_reverse / ori_fwd / ori_rev are inputs of the alignment kernel
     int *bmak;                 // impl 2: per workgroup [32 aligners][32 ring levels] max M antidiagonal (breakpoint pruning)
     // outputs
     uint8_t *is_reverse;       // [npairs]
@@ -118,6 +124,7 @@ int srk_labels(unsigned long long *nodes, uint64_t uf_size, unsigned long long *
 int srk_merge(unsigned long long *nodes, uint64_t uf_size, const unsigned long long *labels,
               uint32_t count, int *error_flag, void *stream);
 int srk_align_max_lds(void);
+int srk_orient(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, void *stream);
 int srk_graph_induce(const unsigned long long *labels, const uint8_t *bases, const uint8_t *islast,
                      uint64_t N, uint64_t uf_size, unsigned long long *first, uint32_t *flag, uint32_t *nid,
                      uint32_t *steps, uint8_t *node_base, unsigned long long *hkeys, uint32_t *hvals,

@@ -1,0 +1,169 @@
+// sr_orient.hip -- orientation pass as its own kernel: one pair per WAVE, no workgroup barriers.
+//
+// Rule (oracle/seqrush.c sro_align_pair; the allwave source is absent): the query is scored
+// forward and reverse-complemented against the target with the one-piece orientation penalties
+// (--orientation-scores, default 0,1,1,1); both aligners advance in lockstep, one score level at a time, and
+// the first to reach the end decides (forward on ties) -- the same predicate as "reverse iff strictly lower".
+//
+// With mismatch 1 there is nothing to block over (M[s] needs M[s-1]), so a level is little work (2 aligners x
+// 1..5 wave tiles); run by a 4-wave workgroup it costs two barriers and a serial set-up per level.  Here every
+// wave owns a pair: levels follow each other without barriers (a wave sees its own stores in order), the
+// ranges are scalar arithmetic, and 16 pairs per CU keep the SIMDs busy.  Tile code = sr_align_blk.inc's
+// blk_tile for one level (4 diagonals per lane, DPP neighbours, 2 halo lanes).
+#include "sr_dev_common.h"
+
+__device__ __forceinline__ int o_lane_left(int x) { return __builtin_amdgcn_update_dpp(NULLV, x, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int o_lane_right(int x) { return __builtin_amdgcn_update_dpp(NULLV, x, 0x130, 0xf, 0xf, false); }
+
+template <typename OT>
+__global__ void __launch_bounds__(64, 4) sr_orient_kernel(SrAlignArgs a) {
+    const int lane = threadIdx.x;
+    const SrPen pen = a.ori;
+    const unsigned w = (unsigned)a.orow;
+    const int depth = pen.scope + 1;
+    GP<OT> ring = (GP<OT>)(OT *)a.oring + (size_t)blockIdx.x * a.oring_wg_stride;
+    GP<OT> nul = ring + (size_t)depth * 3 * w;
+    for (unsigned i = lane; i < w; i += 64) nul[i] = (OT)NULLV;
+    unsigned long long cells = 0, steps = 0;
+    int err = 0;
+#define OROW(LVL, C) (((LVL) < 0) ? nul : ring + (size_t)(((unsigned)((LVL) % depth) * 3u + (unsigned)(C)) * w))
+    for (;;) {
+        int pair = 0;
+        if (lane == 0) pair = (int)atomicAdd(a.oqueue, 1u);
+        pair = RFL(pair);
+        if (pair >= (int)a.npairs) break;
+        const uint32_t q = a.pair_q[pair], t = a.pair_t[pair];
+        const int plen = (int)a.seqlen[q], tlen = (int)a.seqlen[t];
+        const int pw = ((plen + 15) >> 4) + 2, tw = ((tlen + 15) >> 4) + 2;
+        __syncthreads();                                        // (one wave: orders the LDS reuse)
+        load_seq_lds<64>(lds_seq, (GP<const uint32_t>)a.seqwords + a.word_off_fwd[q] - 1, pw);
+        load_seq_lds<64>(lds_seq + a.max_words, (GP<const uint32_t>)a.seqwords + a.word_off_rc[q] - 1, pw);
+        load_seq_lds<64>(lds_seq + 2 * (size_t)a.max_words, (GP<const uint32_t>)a.seqwords + a.word_off_fwd[t] - 1, tw);
+        __syncthreads();
+        const LP T = (LP)(lds_seq + 2 * (size_t)a.max_words + 1);
+        const int shift = plen + 9, width = (plen + tlen + 32) & ~3, kend = tlen - plen;
+        int fwd = -1, rev = INT_MAX, is_rev = 0;
+        const long long smax = (long long)pen.o1 * 2 + (long long)pen.e1 * (plen + tlen) + 64;
+        for (int s = 0;; s++) {
+            const int R = reach(pen, s, SR_C_M);
+            const int klo = max(-plen, -R), khi = min(tlen, R);
+            const int wlo = max(-plen - 1, -R - pen.scope - 1), whi = min(tlen + 1, R + pen.scope + 1);
+            const int glo = (wlo + shift) >> 2, ghi = (whi + shift) >> 2;
+            const int nt = (ghi - glo + 60) / 60;
+            cells += 2ull * (unsigned long long)(khi - klo + 1);
+            steps += 2;
+            GP<OT> rMx = OROW(s - pen.x, 0), rMo = OROW(s - pen.o1 - pen.e1, 0), rI = OROW(s - pen.e1, 1), rD = OROW(s - pen.e1, 2);
+            GP<OT> oM = OROW(s, 0), oI = OROW(s, 1), oD = OROW(s, 2);
+            bool hit[2] = {false, false};
+#pragma unroll
+            for (int job = 0; job < 2; job++) {
+                const LP P = (LP)(lds_seq + (job ? a.max_words : 0) + 1);
+                const int base = job * width;
+                for (int ti = 0; ti < nt; ti++) {
+                    const int g = glo + ti * 60 + lane - 2;
+                    const bool owned = (lane >= 2) && (lane < 62) && (g <= ghi);
+                    const int k0 = (g << 2) - shift;
+                    const unsigned idx0 = (unsigned)(base + (g << 2));
+                    const V4<OT> vmx = ld4<OT>(rMx, idx0), vmo = ld4<OT>(rMo, idx0), vi = ld4<OT>(rI, idx0), vd = ld4<OT>(rD, idx0);
+                    int mx[4], mo[4], si[4], sd[4];
+#pragma unroll
+                    for (int qq = 0; qq < 4; qq++) { mx[qq] = (int)vmx[qq]; mo[qq] = (int)vmo[qq]; si[qq] = (int)vi[qq]; sd[qq] = (int)vd[qq]; }
+                    const int moL = o_lane_left(mo[3]), moR = o_lane_right(mo[0]);
+                    const int iL = o_lane_left(si[3]), dR = o_lane_right(sd[0]);
+                    int mv[4], i1v[4], d1v[4];
+#pragma unroll
+                    for (int qq = 0; qq < 4; qq++) {
+                        const int k = k0 + qq;
+                        const bool inr = (k >= klo) && (k <= khi);
+                        const unsigned lim = (unsigned)min(tlen, plen + k);
+                        const int a1 = (qq == 0) ? moL : mo[qq == 0 ? 0 : qq - 1];
+                        const int b1 = (qq == 0) ? iL : si[qq == 0 ? 0 : qq - 1];
+                        const int c1 = (qq == 3) ? moR : mo[qq == 3 ? 3 : qq + 1];
+                        const int f1 = (qq == 3) ? dR : sd[qq == 3 ? 3 : qq + 1];
+                        int i1 = bnd(max(a1, b1) + 1, lim);
+                        int d1 = bnd(max(c1, f1), lim);
+                        int m = bnd(mx[qq] + 1, lim);
+                        m = max(m, max(i1, d1));
+                        if (!inr) { m = NULLV; i1 = NULLV; d1 = NULLV; }
+                        if (s == 0) { m = (inr && k == 0) ? 0 : NULLV; i1 = NULLV; d1 = NULLV; }
+                        mv[qq] = m; i1v[qq] = i1; d1v[qq] = d1;
+                    }
+                    // extension (same scheme as blk_tile: branch-free first window, then only the cell positions
+                    // some lane still extends)
+                    int more = 0;
+#pragma unroll
+                    for (int qq = 0; qq < 4; qq++) {
+                        const bool valid = owned && mv[qq] >= 0;
+                        const int h = valid ? mv[qq] : 0, v = valid ? mv[qq] - (k0 + qq) : 0;
+                        const int nn = valid ? min(plen - v, tlen - h) : 0;
+                        const uint32_t xw = win_fwd(P, v) ^ win_fwd(T, h);
+                        const unsigned z = (unsigned)(__ffs((int)xw) - 1) >> 1;
+                        const int c = (int)min(min(z, 16u), (unsigned)nn);
+                        mv[qq] += c;
+                        more |= (xw == 0u && nn > 16) ? (1 << qq) : 0;
+                    }
+                    unsigned long long pend[4];
+#pragma unroll
+                    for (int qq = 0; qq < 4; qq++) pend[qq] = __ballot((more >> qq) & 1);
+                    while ((pend[0] | pend[1] | pend[2] | pend[3]) != 0ull) {
+#pragma unroll
+                        for (int qq = 0; qq < 4; qq++) {
+                            if (pend[qq] == 0ull) continue;
+                            const bool on = (more >> qq) & 1;
+                            const int h = on ? mv[qq] : 0, v = on ? mv[qq] - (k0 + qq) : 0;
+                            const int nn = on ? min(plen - v, tlen - h) : 0;
+                            const uint32_t xw = win_fwd(P, v) ^ win_fwd(T, h);
+                            const unsigned z = (unsigned)(__ffs((int)xw) - 1) >> 1;
+                            const int c = (int)min(min(z, 16u), (unsigned)nn);
+                            mv[qq] += c;
+                            if (!(xw == 0u && nn > 16)) more &= ~(1 << qq);
+                            pend[qq] = __ballot((more >> qq) & 1);
+                        }
+                    }
+#pragma unroll
+                    for (int qq = 0; qq < 4; qq++)
+                        hit[job] |= owned && (k0 + qq) == kend && (k0 + qq) >= klo && (k0 + qq) <= khi && mv[qq] >= tlen;
+                    if (owned) {
+                        V4<OT> vM, vI, vD;
+#pragma unroll
+                        for (int qq = 0; qq < 4; qq++) { vM[qq] = (OT)mv[qq]; vI[qq] = (OT)i1v[qq]; vD[qq] = (OT)d1v[qq]; }
+                        st4<OT>(oM, idx0, vM); st4<OT>(oI, idx0, vI); st4<OT>(oD, idx0, vD);
+                    }
+                }
+            }
+            __syncthreads();                                    // one wave: workgroup-scope fence, level s is visible
+            const bool rf = __ballot(hit[0]) != 0ull, rr = __ballot(hit[1]) != 0ull;
+            if (rf) { fwd = s; break; }
+            if (rr) { rev = s; is_rev = 1; break; }
+            if (s > smax) { err |= SR_DEV_ERR_SCORE_BOUND; break; }
+        }
+        if (lane == 0) {
+            a.is_reverse[pair] = is_rev ? 1 : 0;
+            a.ori_fwd[pair] = fwd; a.ori_rev[pair] = rev;
+        }
+    }
+#undef OROW
+    if (lane == 0) {
+        if (cells) { atomicAdd(&a.counters[0], cells); atomicAdd(&a.counters[6], cells); }
+        if (steps) atomicAdd(&a.counters[1], steps);
+        if (err) atomicOr(a.error_flag, err);
+    }
+}
+
+extern "C" int srk_orient(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (off16) {
+        if (lds_bytes > 32 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void *)sr_orient_kernel<int16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL((sr_orient_kernel<int16_t>), dim3(nwg), dim3(64), lds_bytes, st, *a);
+    } else {
+        if (lds_bytes > 32 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void *)sr_orient_kernel<int32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL((sr_orient_kernel<int32_t>), dim3(nwg), dim3(64), lds_bytes, st, *a);
+    }
+    return (int)hipGetLastError();
+}
