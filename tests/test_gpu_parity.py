@@ -454,6 +454,26 @@ def test_all_align_kernels_and_workgroup_sizes(gpu, impl, threads, monkeypatch):
     assert cnt["align_kernel"] == KERNELS[impl]            # one-piece 0,5,8,2 has a blocked instance too
 
 
+@pytest.mark.parametrize("pre", ["0", "1"])
+def test_orientation_kernel_and_in_kernel_orientation_agree(gpu, pre, monkeypatch):
+    """orientation as its own kernel (sr_orient_kernel, one pair per wave; default) and inside the alignment
+    kernel (SR_PREORIENT=0) implement the same lockstep rule: same strands, same orientation scores, same
+    alignments as the oracle -- including RC inputs and non-default orientation penalties"""
+    monkeypatch.setenv("SR_PREORIENT", pre)
+    recs = synth.snp_family(6, 700, 0.05, 181, rc_every=2) + [("short", b"ACGTTGCA"), ("one", b"G")]
+    al, _, cnt = check_parity(recs)
+    assert al.is_reverse.any() and not al.is_reverse.all()
+    check_parity(synth.indel_family(4, 900, 0.04, 0.03, 182), orientation_scores="0,2,3,1")
+    check_parity(synth.indel_family(3, 500, 0.05, 0.02, 183), orientation_scores="0,1,2,2", scores="0,5,8,2")
+    ss = SeqSet(recs); ctx = Context(0); ctx.load(ss, Params()); ctx.align(); ctx.sync()
+    if pre == "1":
+        assert ctx.kernel_ms(4) > 0
+    else:
+        with pytest.raises(sa.SeqRushError):
+            ctx.kernel_ms(4)
+    ctx.close()
+
+
 def test_penalties_without_blocked_instance_fall_back(gpu):
     """the blocked kernel is instantiated for gap-extend (2, 1) and blocks of 5 levels; other penalty sets
     run on the level-synchronous kernel and must match the oracle just the same"""
