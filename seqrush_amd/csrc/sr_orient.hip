@@ -1,6 +1,6 @@
 // sr_orient.hip -- orientation pass as its own kernel: one pair per WAVE, no workgroup barriers.
 //
-// Rule (oracle/seqrush.c sro_align_pair; the allwave source is absent): the query is scored
+// Rule (the allwave source is absent): the query is scored
 // forward and reverse-complemented against the target with the one-piece orientation penalties
 // (--orientation-scores, default 0,1,1,1); both aligners advance in lockstep, one score level at a time, and
 // the first to reach the end decides (forward on ties) -- the same predicate as "reverse iff strictly lower".
