@@ -44,7 +44,7 @@ def test_product_does_not_touch_the_oracle():
     pkg = os.path.join(ROOT, "seqrush_amd")
     for dp, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".cpp", ".hip", ".h")) or f == "Makefile":
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".inc")) or f == "Makefile":
                 txt = open(os.path.join(dp, f)).read()
                 assert "oracle_binding" not in txt and "liboracle" not in txt and "sro_" not in txt, f
 
