@@ -474,6 +474,41 @@ def test_orientation_kernel_and_in_kernel_orientation_agree(gpu, pre, monkeypatc
     ctx.close()
 
 
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_randomised_small_sets(gpu, seed):
+    """seeded random sets: 2-6 sequences of length 1..400 derived from one base by substitutions, indels,
+    truncation at either end and reverse complement -- tiny and ragged inputs through every phase of the default
+    kernels (orientation kernel, blocked search, base cases, unite, graph induction)"""
+    import random
+    rng = random.Random(1000 + seed)
+    L = rng.choice([1, 2, 7, 33, 64, 65, 120, 255, 256, 257, 400])
+    base = synth.to_bytes(synth.base_sequence(L, 2000 + seed))
+    recs = []
+    for i in range(rng.randint(2, 6)):
+        b = bytearray()
+        for ch in base:
+            u = rng.random()
+            if u < 0.04:
+                b.append(rng.choice(b"ACGT"))
+            elif u < 0.06:
+                continue
+            elif u < 0.08:
+                b.append(ch); b.extend(rng.choice(b"ACGT") for _ in range(rng.randint(1, 30)))
+            else:
+                b.append(ch)
+        lo = rng.randint(0, max(0, len(b) // 4)) if rng.random() < 0.3 else 0
+        hi = len(b) - (rng.randint(0, max(0, len(b) // 4)) if rng.random() < 0.3 else 0)
+        sq = bytes(b[lo:hi]) or b"A"
+        if rng.random() < 0.4:
+            sq = synth.reverse_complement(sq)
+        recs.append((f"r{i}", sq))
+    k = rng.choice([0, 0, 1, 5, 20])
+    al, labels, cnt = check_parity(recs, min_match_len=k)
+    ss = SeqSet(recs); ctx = Context(0); ctx.load(ss, Params(min_match_len=k)); ctx.align(); ctx.unite(); ctx.sync()
+    dev = ctx.build_gfa(); ctx.close()
+    assert dev == build_gfa(ss, labels)
+
+
 def test_penalties_without_blocked_instance_fall_back(gpu):
     """the blocked kernel is instantiated for gap-extend (2, 1) and blocks of 5 levels; other penalty sets
     run on the level-synchronous kernel and must match the oracle just the same"""
