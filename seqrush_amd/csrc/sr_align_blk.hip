@@ -4,6 +4,7 @@
 // 16 segments (32 aligners) per pass keep the static LDS of a workgroup below 16 KB: 8 workgroups per CU
 #undef SR_BFS_MAXACT
 #define SR_BFS_MAXACT 16
+#define BFS_MAK_SLOTS SR_BLK_MAK_SLOTS
 #include "sr_align_bfs.inc"
 #ifndef SR_BLK_MIN_WAVES
 #define SR_BLK_MIN_WAVES 4

@@ -412,7 +412,11 @@ extern "C" int sr_ctx_load(sr_ctx *c, const sr_seqset *seqs, const sr_params *p)
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
     // bfs kernel workspace: shared rows (every aligner owns a sub-range) + batched base-case history
     const int brow = (int)((4 * maxlen + 32 * 64 + 64 + 512 + 7) & ~7ULL);     // per-aligner margins + read slack of the last wave tile
-    const int kdepth = std::max(pen.scope + std::max(kblock, 1), ori.scope + 1) + 1;
+    int kdepth = std::max(pen.scope + std::max(kblock, 1), ori.scope + 1) + 1;
+    // lazy I/D rows (sr_align_blk.inc blk_recompute): the M rows must reach 2 * scope + 2 blocks back
+    const char *lz = getenv("SR_LAZY_ID");
+    const int lazy_id = (impl == 2 && !(lz && atoi(lz) == 0) && 2 * pen.scope + 2 * kblock + 2 <= SR_BLK_MAK_SLOTS) ? 1 : 0;
+    if (lazy_id) kdepth = std::max(kdepth, 2 * pen.scope + 2 * kblock + 2);
     uint64_t bring_wg = ((uint64_t)(ring_scope + 1) + 4ULL * ring_hot + 4ULL * (ring_scope + 1) + 2ULL) * (uint64_t)brow;   // + NULL row + U row
     if (impl == 2) bring_wg = ((uint64_t)kdepth * 5 + 2ULL) * (uint64_t)brow + 1024;
     int bbase_jobs = 16;
@@ -460,7 +464,7 @@ extern "C" int sr_ctx_load(sr_ctx *c, const sr_seqset *seqs, const sr_params *p)
         if ((r = dev_alloc(c, &d, (uint64_t)nwg * bseg_wg))) return r; a.bseg = (int *)d;
         if ((r = dev_alloc(c, &d, (uint64_t)nwg * bbt_wg))) return r; a.bbt = (uint32_t *)d;
         if (bcl_wg) { if ((r = dev_alloc(c, &d, (uint64_t)nwg * bcl_wg * 4))) return r; a.bcl = (uint32_t *)d; a.bcl_wg_stride = bcl_wg; }
-        if (impl == 2) { if ((r = dev_alloc(c, &d, (uint64_t)nwg * 32 * 32 * 4))) return r; a.bmak = (int *)d; }
+        if (impl == 2) { if ((r = dev_alloc(c, &d, (uint64_t)nwg * 32 * SR_BLK_MAK_SLOTS * 4))) return r; a.bmak = (int *)d; }
         // orientation as its own kernel, one pair per wave (sr_orient.hip); SR_PREORIENT=0 keeps it in the alignment kernel
         const char *po = getenv("SR_PREORIENT");
         if (impl == 2 && !(po && atoi(po) == 0) && (size_t)max_words * 12 <= 60 * 1024) {
@@ -499,7 +503,7 @@ extern "C" int sr_ctx_load(sr_ctx *c, const sr_seqset *seqs, const sr_params *p)
     a.queue_head = c->d_queue; a.pen = pen; a.ori = ori; a.mem_mode = p->memory_mode;
     a.ring_wg_stride = ring_wg; a.ring_dir_stride = ring_dir; a.ring_cap = ring_cap; a.ring_scope = ring_scope; a.ring_hot = ring_hot;
     a.hist_wg_stride = hist_wg; a.hist_w = hist_w; a.hist_levels = hist_levels;
-    a.impl = impl; a.kdepth = kdepth; a.bring_wg_stride = bring_wg; a.brow = brow; a.bhist_wg_stride = bhist_wg; a.bbase_jobs = bbase_jobs;
+    a.impl = impl; a.kdepth = kdepth; a.lazy_id = lazy_id; a.bring_wg_stride = bring_wg; a.brow = brow; a.bhist_wg_stride = bhist_wg; a.bbase_jobs = bbase_jobs;
     a.cigar_base = d_cbase; a.counters = c->d_counters; a.error_flag = c->d_error;
     SrUniteArgs &u = c->ua;
     memset(&u, 0, sizeof(u));

@@ -12,6 +12,7 @@
 #define SR_BFS_SEGREC 16             // ints per segment record
 #define SR_BFS_MAXACT 32             // segments searched concurrently (2 aligners each)
 #define SR_BFS_BTCAP 1024
+#define SR_BLK_MAK_SLOTS 64           // ring depth the blocked kernel supports
 
 enum { SR_C_M = 0, SR_C_I1 = 1, SR_C_I2 = 2, SR_C_D1 = 3, SR_C_D2 = 4 };
 // raw WFA2 op codes used in device CIGAR ops: (len << 4) | op
@@ -81,6 +82,8 @@ struct SrAlignArgs {
     int orow;
     uint32_t *oqueue;          // pair queue of the orientation kernel
     int pre_oriented;          // 1: is_reverse / ori_fwd / ori_rev are inputs of the alignment kernel
+    int lazy_id;               // impl 2: searches in phase 1 do not store the I/D rows only breakpoint detection reads
+                               //   (kdepth >= 2 * scope + 2 * block + 2 so that they can be recomputed)
     int *bmak;                 // impl 2: per workgroup [32 aligners][32 ring levels] max M antidiagonal (breakpoint pruning)
     // outputs
     uint8_t *is_reverse;       // [npairs]
