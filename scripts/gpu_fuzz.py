@@ -23,7 +23,8 @@ for seed in range(60):
     if rng.random() < 0.3:
         recs = [(nm, sq[rng.randint(0, len(sq) // 5):]) for nm, sq in recs]
     try:
-        t.check_parity(recs)
+        sc = [None, "0,5,8,2", "0,6,9,2,30,1", "0,7,12,2,20,1"][seed % 4]       # blocked+lazy, one-piece, blocked eager, blocked+lazy
+        t.check_parity(recs, **({"scores": sc} if sc else {}))
     except Exception as e:
         bad.append((seed, repr(e)[:200])); print("FAIL medium", seed, repr(e)[:200], flush=True)
     if seed % 10 == 0: print("medium", seed, L, sub, ind, flush=True)
