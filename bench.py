@@ -1,62 +1,141 @@
 #!/usr/bin/env python3
-"""bench.py -- BASELINE.json metric: aligned pairs/s (+GCUPS), all-vs-all
-64 x 5 kb (configs[1], "C2"), hot path = SeqRush::new UF state -> all-vs-all
-biWFA alignment -> match-run extraction -> union-find unite (-> label merge
-across GPUs).  One step = one pass of that path over the whole pair list with
-the packed sequences already resident in HBM.
+"""bench.py -- BASELINE.json metric: aligned pairs/s (+GCUPS), all-vs-all 64 x 5 kb (configs[1], "C2").
+Hot path = SeqRush::new UF state -> (orientation ->) all-vs-all biWFA alignment -> match-run extraction ->
+union-find unite (-> label merge across GPUs).  One step = one pass of that path over the whole pair list with the
+packed sequences already resident in HBM.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config C2|C3|C4|C5]
     (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-Rank 0 prints ONE JSON line.  The pair list is sharded over ranks (strong
-scaling: the n^2 list is fixed); per-rank forests are merged with one RCCL
-all-gather of canonical labels + replay-unite.
+Rank 0 prints ONE JSON line.  The pair list is sharded over ranks (cost-balanced; strong scaling: the list is
+fixed); per-rank forests are merged with one RCCL all-gather of canonical u32 labels + replay-unite.
+
+roofline (dominant kernel = the alignment kernel):
+  achieved  = the kernel's row traffic, counted on the device lane access by lane access (every tile's row loads and
+              stores; sr_align_blk.inc), divided by the kernel's average launch time (hipEvents on its stream)
+  traffic   = HBM bytes per launch from the rocprofv3 PMC passes of the same command, FETCH_SIZE x 2.00 +
+              WRITE_SIZE x 1.00 (factors calibrated on this access shape by scripts/calib, profiles/r02_calibration.json)
+  valu_issue_frac = SQ_INSTS_VALU / (SIMDs x busy cycles x 0.5 wave-instructions per cycle and SIMD)
+The PMC-derived fields come from profiles/r02_counters.json (written by scripts/profile_round.sh in the same round);
+they are per launch of this same C2 workload.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-BYTES_PER_CELL_2P = 28    # 9 loads + 5 stores of 2-byte offsets per (score,diagonal) cell
-HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s measured for streaming copies)
 
 
-def cpu_baseline(recs, sample_pairs):
-    """oracle ("port") timed on the host cores over a bounded sample of the same pair list"""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_binding as ob
-    cores = os.cpu_count() or 1
+def usable_cpus():
+    """CPUs this process may really use: affinity mask capped by the cgroup quota (cpu.max)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
     try:
-        cores = len(os.sched_getaffinity(0))
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(per)
     except Exception:
         pass
-    o = ob.OracleSeqRush(records=recs)
-    p = ob.default_params()
-    p.threads = cores
-    t0 = time.perf_counter()
-    done, cells = o.align_and_unite(p, 0, sample_pairs)
-    dt = time.perf_counter() - t0
-    o.close()
-    return {"value": done / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": f"first {done} ordered pairs (row-major) of the same 64x5kb set, "
-                      f"{dt:.1f} s wall, oracle/ C restatement with OpenMP over pairs",
-            "gcups": cells / dt / 1e9}
+    return max(1, min(n, int(quota) if quota and quota >= 1 else n)), n, quota
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(recs, pairs, total_pairs_label):
+    """the oracle ("port": C restatement, OpenMP over pairs, one aligner arena per thread,
+    lock-free UF) on the host, legs -t 1, -t 4 (the reference's default, src/seqrush.rs:37) and all usable cores
+    (cgroup quota honoured), threads confined to as many distinct cores, 3 runs each, median.  Every leg aligns a
+    bounded prefix of the SAME ordered pair list the GPU runs."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+    usable, affinity_n, quota = usable_cpus()
+    all_cpus = sorted(os.sched_getaffinity(0))
+    # distinct physical cores first: on the pool's hosts logical cpu i and i + n/2 are SMT siblings
+    legs = []
+    for t in sorted({1, min(4, usable), usable}):
+        legs.append(t)
+    out_legs = {}
+    saved = os.sched_getaffinity(0)
+    try:
+        for t in legs:
+            os.sched_setaffinity(0, set(all_cpus[:t]))
+            npairs = min(len(pairs), max(12, 6 * t) if len(recs[0][1]) >= 4000 else 64 * t)
+            sample = pairs[:npairs]
+            vals, cells_v = [], []
+            for _ in range(3):
+                o = ob.OracleSeqRush(records=recs)
+                p = ob.default_params()
+                p.threads = t
+                t0 = time.perf_counter()
+                done, cells = o.align_and_unite_list(p, sample)
+                dt = time.perf_counter() - t0
+                o.close()
+                vals.append(done / dt); cells_v.append(cells / dt / 1e9)
+            med = statistics.median(vals)
+            out_legs[f"t{t}"] = {"threads": t, "pairs_per_s": med, "pairs_per_s_per_thread": med / t,
+                                 "gcups": statistics.median(cells_v), "runs": vals, "sample_pairs": npairs}
+    finally:
+        os.sched_setaffinity(0, saved)
+    best = max(out_legs.values(), key=lambda d: d["pairs_per_s"])
+    return {"value": best["pairs_per_s"], "unit": "pairs/s", "cores": best["threads"], "kind": "port",
+            "sample": f"first {best['sample_pairs']} ordered pairs of the same list ({total_pairs_label}), median of 3 runs per leg, "
+                      f"oracle/ C restatement (OpenMP over pairs, per-thread arenas, 64-bit word extension), threads "
+                      f"confined to {best['threads']} cpus",
+            "legs": out_legs,
+            "host": {"cpu_model": cpu_model(), "logical_cpus_visible": affinity_n, "cgroup_cpu_quota": quota,
+                     "usable_cpus": usable}}
+
+
+def build_config(name, nseq):
+    from seqrush_amd import synth
+    if name == "C2":
+        recs = synth.config_c2(nseq)
+        return recs, "none", (f"C2: {nseq} x 5 kb synthetic (5% SNP, seed 2001), all-vs-all incl. self = {nseq * nseq} "
+                              f"ordered pairs"), f"aligned pairs/sec all-vs-all {nseq}x5kb"
+    if name == "C3":
+        recs = synth.config_c3_surrogate()
+        return recs, "none", ("C3 surrogate: 12 x ~14 kb (3% substitutions, 0.3% indels, two 200-800 bp insertions each; "
+                              "HLA-zoo DRB1 is not in the container), all-vs-all incl. self = 144 ordered pairs"), \
+            "aligned pairs/sec all-vs-all C3 surrogate 12x14kb"
+    if name == "C4":
+        recs = synth.config_c4()
+        return recs, "tree:3,3,0.1", "C4: 1024 x 2 kb synthetic (16 clades), -x tree:3,3,0.1", \
+            "aligned pairs/sec 1024x2kb tree:3,3,0.1"
+    if name == "C5":
+        recs = synth.config_c5()
+        return recs, "none", ("C5: 256 x 50 kb synthetic (2% substitutions, 0.1% indels, in-place inversions in 25%, 10% "
+                              "reverse-complemented), all-vs-all incl. self = 65536 ordered pairs"), \
+            "aligned pairs/sec all-vs-all 256x50kb"
+    raise SystemExit(f"unknown --config {name}")
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--nseq", type=int, default=64)
-    ap.add_argument("--cpu-sample-pairs", type=int, default=0,
-                    help="pairs in the CPU-baseline sample (0 = 8 per host core, at least 256)")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", default="C2", choices=["C2", "C3", "C4", "C5"])
+    ap.add_argument("--nseq", type=int, default=64, help="C2 only: number of 5 kb sequences")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 1 if args.config == "C5" else 5
+    if args.warmup is None:
+        args.warmup = 0 if args.config == "C5" else 1
 
     import torch
     import torch.distributed as dist
@@ -85,37 +164,42 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
         dist.barrier()
 
-    from seqrush_amd import synth
     from seqrush_amd.seqrush import SeqSet, Params, Context
 
-    recs = synth.config_c2(args.nseq)
+    recs, spars, workload, metric = build_config(args.config, args.nseq)
     ss = SeqSet(recs)
-    prm = Params()
+    prm = Params(sparsification=spars)
     prm.c.device = dev
     prm.c.shard_rank, prm.c.shard_count = rank, world
     ctx = Context(dev)
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
-    ctx.load(ss, prm)                      # pack + upload: inputs resident before timing
+    ctx.load(ss, prm)                      # pack + upload (+ sketches): inputs resident before timing
     ufn = ctx.uf_size
-    lab = torch.empty(ufn, dtype=torch.int64, device="cuda")
-    gathered = torch.empty(ufn * world, dtype=torch.int64, device="cuda") if world > 1 else None
-    total_pairs = args.nseq * args.nseq
-    total_cells = sum(len(a[1]) for a in recs) ** 2
+    u32 = ufn < (1 << 32)                  # u32 labels while 2N+2 < 2^32
+    ldt = torch.int32 if u32 else torch.int64
+    lab = torch.empty(ufn, dtype=ldt, device="cuda") if world > 1 else None
+    gathered = torch.empty(ufn * world, dtype=ldt, device="cuda") if world > 1 else None
+    my_pairs = ctx.pairs()
+    tp = torch.tensor([len(my_pairs), ctx.dp_cells], dtype=torch.float64)
+    if world > 1:
+        tpd = tp.to("cpu" if single_dev else "cuda")
+        dist.all_reduce(tpd)
+        tp = tpd.cpu()
+    total_pairs, total_cells = int(tp[0].item()), float(tp[1].item())
 
     def step():
         ctx.reset_uf()
-        ctx.align()
-        ctx.unite()
+        ctx.run()                          # (orientation +) alignment + unite, batch after batch
         if world > 1:
-            ctx.labels_device(lab.data_ptr())
+            (ctx.labels_device_u32 if u32 else ctx.labels_device)(lab.data_ptr())
             if single_dev:
-                parts = [torch.empty(ufn, dtype=torch.int64) for _ in range(world)]
+                parts = [torch.empty(ufn, dtype=ldt) for _ in range(world)]
                 dist.all_gather(parts, lab.cpu())
                 gathered.copy_(torch.cat(parts))
             else:
                 dist.all_gather_into_tensor(gathered, lab)
-            ctx.merge_labels(gathered.data_ptr(), world)
+            (ctx.merge_labels_u32 if u32 else ctx.merge_labels)(gathered.data_ptr(), world)
 
     def fence():
         if world > 1:
@@ -126,22 +210,20 @@ def main():
         step()
     fence()
     ctx.sync()
-    align_ms = []
-    unite_ms = []
-    orient_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        # event timers are read after the timed region for the last step only;
-        # per-step values are collected without host sync below
     fence()
     dt = time.perf_counter() - t0
     ctx.sync()                              # raises on device fault bits
-    # per-kernel durations: re-run K untimed steps with event reads (keeps the
-    # timed region free of host syncs)
-    for _ in range(args.steps):
-        step()
-        torch.cuda.synchronize()
+    # per-kernel durations (hipEvents on the context's stream): for the long configs the timed steps' own events
+    # are read; otherwise K more untimed steps with event reads keep the timed region free of host syncs
+    align_ms, unite_ms, orient_ms = [], [], []
+    reread = args.config != "C5"
+    for _ in range(args.steps if reread else 1):
+        if reread:
+            step()
+            torch.cuda.synchronize()
         align_ms.append(ctx.kernel_ms(0))
         unite_ms.append(ctx.kernel_ms(1))
         try:
@@ -149,6 +231,7 @@ def main():
         except Exception:
             pass
     cnt = ctx.counters()
+    rep = ctx.workspace_report()
     labels_sha = None
     if os.environ.get("SR_BENCH_LABEL_SHA") == "1":
         import hashlib
@@ -163,45 +246,48 @@ def main():
         a_ms = sum(align_ms) / len(align_ms)
         u_ms = sum(unite_ms) / len(unite_ms)
         o_ms = sum(orient_ms) / len(orient_ms) if orient_ms else None
-        # wavefront cells of the dominant kernel: the orientation kernel's cells are counted apart ([6])
-        ori_cells = cnt["ticks_orientation"] if orient_ms else 0
+        ori_cells = cnt["ticks_orientation"] if orient_ms else 0      # [6] = the orientation kernel's cells
         cells = cnt["wf_cells"] - ori_cells
-        alg_bytes = cells * BYTES_PER_CELL_2P + ctx.num_pairs * (2 * 1250 * 2 + 8 * 1024)
-        achieved = alg_bytes / (a_ms * 1e-3) / 1e9
-        align_kernel_name = ctx.align_kernel
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        if world == 1 and os.path.exists(tpath):
+        row_bytes = cnt["row_bytes_loaded"] + cnt["row_bytes_stored"]
+        achieved = row_bytes / (a_ms * 1e-3) / 1e9 if a_ms > 0 else 0.0
+        pmc = {}
+        ppath = os.path.join(ROOT, "profiles", "r02_counters.json")
+        if world == 1 and args.config == "C2" and args.nseq == 64 and os.path.exists(ppath):
             try:
-                traffic = json.load(open(tpath)).get("sr_align_kernel_bytes_per_launch")
+                pmc = json.load(open(ppath))
             except Exception:
-                traffic = None
+                pmc = {}
+        roof = {"bound": "hbm", "kernel": ctx.align_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc.get("align_hbm_bytes_per_launch"),
+                "kernel_ms": a_ms, "row_bytes_loaded_per_launch": cnt["row_bytes_loaded"],
+                "row_bytes_stored_per_launch": cnt["row_bytes_stored"], "wf_cells_per_launch": cells,
+                "bytes_per_cell": row_bytes / cells if cells else None,
+                "traffic_frac_of_peak": (pmc["align_hbm_bytes_per_launch"] / (pmc["align_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                if pmc.get("align_hbm_bytes_per_launch") and pmc.get("align_kernel_ms") else None,
+                "valu_issue_frac": pmc.get("align_valu_issue_frac"),
+                "pmc_source": "profiles/r02_counters.json" if pmc else None,
+                "unite_kernel_ms": u_ms, "orient_kernel_ms": o_ms, "orient_wf_cells_per_launch": ori_cells,
+                "wf_cells_per_s": cells / (a_ms * 1e-3) if a_ms > 0 else None}
+        if roof["valu_issue_frac"] and roof["valu_issue_frac"] > max(roof["frac"], roof["traffic_frac_of_peak"] or 0):
+            roof["bound"] = "valu"
         out = {
-            "metric": "aligned pairs/sec all-vs-all 64x5kb",
-            "value": total_pairs * args.steps / dt,
-            "unit": "pairs/s",
+            "metric": metric, "value": total_pairs * args.steps / dt, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "i32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "i16" if rep.get("offset_bytes") == 2 else "i32", "data": "synthetic",
             "gcups": total_cells * args.steps / dt / 1e9,
-            "config": {"workload": f"C2: {args.nseq} x 5 kb synthetic (5% SNP, seed 2001), all-vs-all "
-                                   f"incl. self = {total_pairs} ordered pairs, -k 0 -S 0,5,8,2,24,1 "
-                                   f"--orientation-scores 0,1,1,1, biWFA (Ultralow)",
-                       "pairs_per_gpu": ctx.num_pairs, "parallelism": f"pair-shard x{world}"},
-            "roofline": {"bound": "hbm", "kernel": align_kernel_name, "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel_ms": a_ms, "wf_cells_per_launch": cells,
-                         "bytes_per_cell": BYTES_PER_CELL_2P, "unite_kernel_ms": u_ms,
-                         "orient_kernel_ms": o_ms, "orient_wf_cells_per_launch": ori_cells,
-                         "wf_cells_per_s": cells / (a_ms * 1e-3)},
+            "config": {"workload": workload + ", -k 0 -S 0,5,8,2,24,1 --orientation-scores 0,1,1,1, biWFA (Ultralow)",
+                       "pairs_total": total_pairs, "pairs_per_gpu": ctx.num_pairs,
+                       "parallelism": f"pair-shard x{world} (cost-balanced), u32 label all-gather" if world > 1 else "pair-shard x1",
+                       "workspace": rep},
+            "roofline": roof,
             "kernels": cnt,
         }
         if labels_sha:
             out["labels_sha256"] = labels_sha
         if world == 1 and not args.no_cpu_baseline:
-            ncore = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            sample = args.cpu_sample_pairs or max(256, 8 * ncore)
-            out["cpu_baseline"] = cpu_baseline(recs, min(sample, total_pairs))
+            out["cpu_baseline"] = cpu_baseline(recs, my_pairs, workload.split(":")[0])
+            out["speedup_vs_cpu_best_leg"] = out["value"] / out["cpu_baseline"]["value"]
     ctx.close()
     if world > 1:
         dist.barrier()

@@ -21,14 +21,14 @@
 extern "C" {
 #endif
 
-#define SR_ABI_VERSION 1
+#define SR_ABI_VERSION 2
 
 typedef enum {
     SR_OK = 0,
     SR_ERR_INVALID = -1,      /* bad argument / parse error */
     SR_ERR_NO_DEVICE = -2,    /* no HIP device or HIP runtime failure at init */
     SR_ERR_HIP = -3,          /* a HIP call failed */
-    SR_ERR_ALPHABET = -4,     /* sequence byte outside the packable alphabet */
+    SR_ERR_ALPHABET = -4,     /* (unused since ABI 2: every byte value is accepted, like the reference's raw-byte compare) */
     SR_ERR_EMPTY_SEQ = -5,    /* "Empty sequences are not allowed" seqrush.rs:310-317 */
     SR_ERR_UNSUPPORTED = -6,  /* parameter combination not implemented on device */
     SR_ERR_DEVICE_FAULT = -7, /* kernel reported an internal bound violation */
@@ -47,7 +47,8 @@ typedef struct {
     const char *const *names;     /* n C strings (may be NULL for unite-only use) */
 } sr_seqset;
 
-/* lib_wfa2 MemoryMode as used by src/wfa.rs:57,65 */
+/* lib_wfa2 MemoryMode as used by src/wfa.rs:57,65.  The reference always selects Ultralow (= biWFA); the device
+ * keeps full wavefront history only for biWFA's base cases, so SR_MEM_HIGH is refused with SR_ERR_UNSUPPORTED. */
 #define SR_MEM_HIGH 0
 #define SR_MEM_ULTRALOW 3
 
@@ -61,7 +62,8 @@ typedef struct {
 /* sr_params mirrors allwave::AlignmentParams (src/seqrush.rs:648-666) plus
  * the Args fields the hot path reads (-k, -d, -x; src/seqrush.rs:24-151). */
 typedef struct {
-    int32_t match_score;        /* must be 0 */
+    int32_t match_score;        /* must be 0: seqrush.rs:45; the trait impl's own 2,4,4,2,24,1 (allwave_impl.rs:15-23)
+                                   is refused, allwave's conversion of a positive match score is not in the reference tree */
     int32_t mismatch_penalty;   /* -S default 0,5,8,2,24,1 (seqrush.rs:45) */
     int32_t gap_open1, gap_ext1;
     int32_t gap_open2, gap_ext2;        /* < 0 : single-piece affine */
@@ -70,14 +72,20 @@ typedef struct {
     double max_divergence;      /* -d, < 0 = None */
     int32_t exclude_self;       /* reference passes false (:731) */
     int32_t memory_mode;        /* SR_MEM_ULTRALOW = reference (wfa.rs:57) */
-    int32_t sparsify_kind;      /* SR_SPARSE_* ; only NONE/RANDOM on device */
-    double sparsify_factor;
+    int32_t sparsify_kind;      /* SR_SPARSE_* (grammar seqrush.rs:356-431).  allwave's selection rules are absent from the
+                                   reference tree: the definitions (sr_host.cpp "pair list", sr_sketch.hip) are this
+                                   project's own and unpinned, random:F included */
+    double sparsify_factor;     /* random:F / connectivity:P */
     uint64_t sparsify_seed;
     int32_t canonical_labels;   /* sr_align_and_unite: 1 = return min-Pos labels */
     int32_t device;             /* HIP device ordinal */
     /* pair shard for multi-GPU: this call handles ordered pairs whose index
      * in the (sparsified) row-major n*n list is == shard_rank mod shard_count */
     uint32_t shard_rank, shard_count;
+    /* tree:neighbor[,stranger[,random[,k-mer]]] (seqrush.rs:378-418; extract_tree_pairs_separated call :941-947) */
+    uint32_t tree_k_nearest, tree_k_farthest;
+    double tree_rand_frac;
+    uint32_t tree_kmer;         /* default 16; 1..32 on the device */
 } sr_params;
 
 void sr_default_params(sr_params *p);
@@ -89,7 +97,9 @@ int sr_parse_sparsification(const char *s, sr_params *p);
 
 /* This rank's ordered pair list (host only, no device needed): what
  * AllPairIterator::with_options(.., exclude_self, .., sparsification) enumerates
- * (src/seqrush.rs:728-735), sharded for multi-GPU.  Free both arrays with sr_free. */
+ * (src/seqrush.rs:728-735), sharded for multi-GPU (equal sequence lengths assumed: sr_ctx_pairs gives the
+ * cost-balanced shard of a loaded context).  tree: needs the sequences -> SR_ERR_UNSUPPORTED here.
+ * Free both arrays with sr_free. */
 int sr_pair_list(uint32_t n, const sr_params *p, uint32_t **q_out, uint32_t **t_out,
                  uint64_t *count);
 
@@ -139,14 +149,36 @@ int sr_ctx_create(int device, sr_ctx **out);
 void sr_ctx_destroy(sr_ctx *c);
 /* optional: launch on an externally owned hipStream_t */
 int sr_ctx_set_stream(sr_ctx *c, void *hip_stream);
-/* pack (2-bit fwd + reverse complement) and upload; SeqRush::new UF init */
+/* pack (2 / 4 / 8 bits per symbol by alphabet; forward + reverse complement) and upload; pair list (sparsified:
+ * k-mer sketches on the device), cost-balanced shard, SeqRush::new UF init */
 int sr_ctx_load(sr_ctx *c, const sr_seqset *seqs, const sr_params *p);
+/* the same with an explicit ordered pair list instead of the enumeration: the per-pair call pattern of the
+ * reference's iterative mode (AllPairIterator over a 2-sequence slice, src/seqrush.rs:984-1012) and of
+ * seqrush_clean (src/seqrush_clean.rs:289-292) without re-uploading the sequences; sharded like sr_ctx_load */
+int sr_ctx_load_pairs(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const uint32_t *query_idx,
+                      const uint32_t *target_idx, uint64_t count);
+/* this rank's pair list of the loaded context (after sparsification and sharding); free with sr_free */
+int sr_ctx_pairs(const sr_ctx *c, uint32_t **q_out, uint32_t **t_out, uint64_t *count);
+/* The CIGAR arena holds |q|+|t|+2 ops per pair; when the shard's pairs do not fit device memory at once they run in
+ * batches that reuse it (1 for every BASELINE config up to C4; C5 on one GPU: several) */
+uint32_t sr_ctx_num_batches(const sr_ctx *c);
+/* JSON object describing the sizing of the last load (workgroups, ring / history / arena bytes ...) */
+const char *sr_ctx_workspace_report(const sr_ctx *c);
 /* reset the UF to the SeqRush::new state (seqrush.rs:324-328) */
 int sr_ctx_reset_uf(sr_ctx *c);
-/* enqueue alignment kernel(s) for this rank's pair shard (no host sync) */
+/* enqueue alignment kernel(s) for this rank's pair shard (no host sync); single-batch contexts only */
 int sr_ctx_align(sr_ctx *c);
-/* enqueue match-run extraction + unite kernel (no host sync) */
+/* enqueue match-run extraction + unite kernel (no host sync); single-batch contexts only */
 int sr_ctx_unite(sr_ctx *c);
+/* align + unite of the whole shard, batch after batch (no host sync): == sr_ctx_align + sr_ctx_unite when there
+ * is one batch; for a PAF context: unite only */
+int sr_ctx_run(sr_ctx *c);
+/* Seam 1 on a loaded context: every alignment of the shard on the host (batches are copied out one after the
+ * other); unite != 0 also unites each batch (--output-alignments without the reference's second pass) */
+int sr_ctx_align_all(sr_ctx *c, int unite, sr_alignments **out);
+/* per-pair results that stay resident across batches (arrays of sr_ctx_num_pairs; NULL = skip): score (-1 = failed),
+ * strand flag, number of run-length CIGAR ops */
+int sr_ctx_pair_results(sr_ctx *c, int32_t *score, uint8_t *is_reverse, uint32_t *cigar_ops);
 int sr_ctx_sync(sr_ctx *c);     /* stream sync + device error flags */
 /* results */
 int sr_ctx_alignments(sr_ctx *c, sr_alignments **out);       /* after sync */
@@ -160,6 +192,9 @@ uint64_t sr_ctx_dp_cells(const sr_ctx *c);   /* sum |q|*|t| over this shard */
  * laid out back to back in DEVICE memory. */
 int sr_ctx_labels_device(sr_ctx *c, uint64_t *dev_labels);
 int sr_ctx_merge_labels(sr_ctx *c, const uint64_t *dev_labels, uint32_t count);
+/* the same exchange with 32-bit labels (valid while 2N+2 < 2^32: half the all-gather bytes) */
+int sr_ctx_labels_device_u32(sr_ctx *c, uint32_t *dev_labels);
+int sr_ctx_merge_labels_u32(sr_ctx *c, const uint32_t *dev_labels, uint32_t count);
 int sr_ctx_download_labels(sr_ctx *c, uint64_t *labels_out);
 /* Seam 3, input side (`seqrush -p file.paf`, src/seqrush.rs:510-609): replaces sr_ctx_load + sr_ctx_align.
  * Every record of the PAF file whose names are known and that carries a cg:Z: tag is replayed through
@@ -189,6 +224,10 @@ const char *sr_ctx_align_kernel(const sr_ctx *c);
  * search passes; [10] ticks of whole pairs; [11..15] ticks inside the breakpoint
  * search: wavefront pass, barrier wait, phase-1 control, breakpoint detection, tail */
 int sr_ctx_counters(sr_ctx *c, uint64_t out[16]);
+/* the same plus [16] bytes of wavefront rows loaded, [17] stored by the alignment kernel's tiles (every lane access of
+ * every tile counted on the device: the kernel's algorithmic HBM bytes, bench.py roofline); [18..31] reserved.
+ * The tick counters [6..15] are filled only by the instrumented kernel instance (environment SR_PROFILE_TICKS=1). */
+int sr_ctx_counters_ext(sr_ctx *c, uint64_t out[32]);
 
 /* -------- consumer (A9): graph induction + GFA, host C++ -----------------
  * build_bidirected_graph_with_options (bidirected_builder.rs:17-289) +

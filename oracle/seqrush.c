@@ -452,6 +452,165 @@ int64_t sro_align_and_unite(sro_seqrush *s, const sro_params *p,
     return failed ? -1 : done;
 }
 
+/* the same over an explicit ordered pair list (sparsified lists, explicit lists) */
+int64_t sro_align_and_unite_list(sro_seqrush *s, const sro_params *p, const uint32_t *pq, const uint32_t *pt,
+                                 uint64_t count, uint64_t *dp_cells) {
+    int64_t done = 0;
+    uint64_t cells = 0;
+    int failed = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(p->threads > 0 ? p->threads : 1) reduction(+:done,cells)
+#endif
+    for (uint64_t idx = 0; idx < count; idx++) {
+        const uint32_t q = pq[idx], t = pt[idx];
+        sro_alignment a;
+        if (sro_align_pair(s, p, q, t, &a)) { failed = 1; continue; }
+        cells += s->seqs[q].len * s->seqs[t].len;
+        int keep = 1;
+        if (p->max_divergence >= 0.0) {
+            uint64_t L = s->seqs[q].len < s->seqs[t].len ? s->seqs[q].len : s->seqs[t].len;
+            if (a.score > sro_max_score_for_divergence(&p->pen, L, p->max_divergence)) keep = 0;
+        }
+        if (keep) {
+            char *cig = sro_cigar_bytes_to_string(a.cigar_bytes, a.cigar_len);
+            int64_t r = sro_process_alignment(s, cig, q, t, p->min_match_len, a.is_reverse,
+                                              0, s->seqs[q].len, 0, s->seqs[t].len);
+            if (r < 0) failed = 1;
+            free(cig);
+        }
+        sro_alignment_free(&a);
+        done++;
+    }
+    if (dp_cells) *dp_cells = cells;
+    return failed ? -1 : done;
+}
+
+/* ------------------------------------------------------------------ */
+/* pair sparsification (grammar seqrush.rs:356-431; the selection rules live in the absent allwave crate:    */
+/* this is the project's own definition, the same one the product implements -- PARITY UNPINNED)             */
+/*   random:F        ordered pair (q,t), q != t, kept iff unit(mix(seed ^ (q*n+t))) < F                         */
+/*   connectivity:P  unordered {i<j} kept iff unit(mix(seed ^ (i*n+j))) < min(1, (ln n - ln(-ln P)) / n)       */
+/*   auto            n < 10: none, else connectivity:0.99                                                      */
+/*   tree:kn,kf,rf,k unordered pair kept iff one of the kn nearest / kf farthest neighbours of either end by   */
+/*                   bottom-1000 sketch similarity of canonical k-mers, or unit(mix(seed ^ (i*n+j))) < rf      */
+/* self pairs are always kept unless exclude_self; both directions of a kept unordered pair are aligned        */
+/* ------------------------------------------------------------------ */
+static uint64_t sp_mix(uint64_t x) {
+    x += 0x9e3779b97f4a7c15ULL;
+    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    x = (x ^ (x >> 27)) * 0x94d049bb133111ebULL;
+    return x ^ (x >> 31);
+}
+static double sp_unit(uint64_t h) { return (double)(h >> 11) * (1.0 / 9007199254740992.0); }
+static int sp_code(uint8_t b) {
+    switch (b) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2;
+                 case 'T': case 't': return 3; default: return -1; }
+}
+static int sp_cmp_u64(const void *a, const void *b) {
+    const uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+#define SP_SKETCH 1000
+/* bottom-SP_SKETCH distinct canonical k-mer hashes of one sequence, ascending; returns the count */
+static uint32_t sp_sketch(const sro_sequence *q, int k, uint64_t *out) {
+    if (q->len < (uint64_t)k) return 0;
+    const uint64_t nk = q->len - (uint64_t)k + 1;
+    uint64_t *h = (uint64_t *)malloc(sizeof(uint64_t) * nk);
+    uint64_t m = 0;
+    const uint64_t salt = (uint64_t)k * 0x9E3779B97F4A7C15ULL;
+    for (uint64_t i = 0; i < nk; i++) {
+        uint64_t f = 0, r = 0;
+        int ok = 1;
+        for (int j = 0; j < k; j++) {
+            const int c = sp_code(q->data[i + (uint64_t)j]);
+            if (c < 0) { ok = 0; break; }
+            f = (f << 2) | (uint64_t)c;
+            r |= (uint64_t)(3 - c) << (2 * j);
+        }
+        if (!ok) continue;
+        const uint64_t v = sp_mix((f < r ? f : r) ^ salt);
+        if (v != UINT64_MAX) h[m++] = v;
+    }
+    qsort(h, m, sizeof(uint64_t), sp_cmp_u64);
+    uint32_t cnt = 0;
+    for (uint64_t i = 0; i < m && cnt < SP_SKETCH; i++)
+        if (i == 0 || h[i] != h[i - 1]) out[cnt++] = h[i];
+    free(h);
+    return cnt;
+}
+
+int sro_sparsified_pairs(const sro_seqrush *s, const sro_sparsification *sp, uint64_t seed, int exclude_self,
+                         uint32_t **pq_out, uint32_t **pt_out, uint64_t *count) {
+    const uint64_t n = s->n;
+    int kind = sp->kind;
+    double frac = sp->factor;
+    if (kind == SRO_SPARSE_AUTO) { if (n < 10) kind = SRO_SPARSE_NONE; else { kind = SRO_SPARSE_CONNECTIVITY; frac = 0.99; } }
+    double conn_f = 1.0;
+    if (kind == SRO_SPARSE_CONNECTIVITY && n > 2 && frac < 1.0) {
+        const double c = -log(-log(frac));
+        conn_f = (log((double)n) + c) / (double)n;
+        if (conn_f > 1.0) conn_f = 1.0;
+        if (conn_f < 0.0) conn_f = 0.0;
+    }
+    uint8_t *sel = NULL;
+    if (kind == SRO_SPARSE_TREE && n > 1) {
+        if (sp->kmer_size < 1 || sp->kmer_size > 32) return -1;
+        uint64_t *sk = (uint64_t *)malloc(sizeof(uint64_t) * n * SP_SKETCH);
+        uint32_t *skn = (uint32_t *)malloc(sizeof(uint32_t) * n);
+        for (uint64_t i = 0; i < n; i++) skn[i] = sp_sketch(&s->seqs[i], (int)sp->kmer_size, sk + i * SP_SKETCH);
+        uint32_t *sh = (uint32_t *)calloc(n * n, sizeof(uint32_t)), *dn = (uint32_t *)calloc(n * n, sizeof(uint32_t));
+        for (uint64_t i = 0; i < n; i++)
+            for (uint64_t j = i + 1; j < n; j++) {
+                const uint64_t *A = sk + i * SP_SKETCH, *B = sk + j * SP_SKETCH;
+                uint32_t x = 0, y = 0, shared = 0, denom = 0;
+                while (denom < SP_SKETCH && (x < skn[i] || y < skn[j])) {
+                    if (y >= skn[j] || (x < skn[i] && A[x] < B[y])) x++;
+                    else if (x >= skn[i] || B[y] < A[x]) y++;
+                    else { x++; y++; shared++; }
+                    denom++;
+                }
+                if (denom == 0) denom = 1;
+                sh[i * n + j] = sh[j * n + i] = shared; dn[i * n + j] = dn[j * n + i] = denom;
+            }
+        sel = (uint8_t *)calloc(n * n, 1);
+        const uint64_t kn = sp->k_nearest < n ? sp->k_nearest : n, kf = sp->k_farthest < n ? sp->k_farthest : n;
+        for (uint64_t i = 0; i < n; i++) {
+            uint8_t *row = sel + i * n;
+            for (uint64_t pass = 0; pass < kn + kf; pass++) {
+                const int nearest = pass < kn;
+                int64_t best = -1;
+                for (uint64_t j = 0; j < n; j++) {
+                    if (j == i || (row[j] & (nearest ? 1 : 2))) continue;
+                    if (best < 0) { best = (int64_t)j; continue; }
+                    const uint64_t l = (uint64_t)sh[i * n + j] * dn[i * n + (uint64_t)best];
+                    const uint64_t r = (uint64_t)sh[i * n + (uint64_t)best] * dn[i * n + j];
+                    if (nearest ? (l > r) : (l < r)) best = (int64_t)j;
+                }
+                if (best < 0) break;
+                row[best] |= nearest ? 1 : 2;
+            }
+        }
+        free(sk); free(skn); free(sh); free(dn);
+    }
+    const uint64_t cap = n ? n * n : 1;
+    uint32_t *pq = (uint32_t *)malloc(sizeof(uint32_t) * cap), *pt = (uint32_t *)malloc(sizeof(uint32_t) * cap);
+    uint64_t m = 0;
+    for (uint64_t q = 0; q < n; q++)
+        for (uint64_t t = 0; t < n; t++) {
+            if (q == t) { if (exclude_self) continue; pq[m] = (uint32_t)q; pt[m] = (uint32_t)t; m++; continue; }
+            const uint64_t i = q < t ? q : t, j = q < t ? t : q;
+            int keep = 1;
+            if (kind == SRO_SPARSE_RANDOM) keep = sp_unit(sp_mix(seed ^ (q * n + t))) < frac;
+            else if (kind == SRO_SPARSE_CONNECTIVITY) keep = sp_unit(sp_mix(seed ^ (i * n + j))) < conn_f;
+            else if (kind == SRO_SPARSE_TREE)
+                keep = (sel && (sel[i * n + j] || sel[j * n + i])) || sp_unit(sp_mix(seed ^ (i * n + j))) < sp->rand_frac;
+            if (keep) { pq[m] = (uint32_t)q; pt[m] = (uint32_t)t; m++; }
+        }
+    free(sel);
+    *pq_out = pq; *pt_out = pt; *count = m;
+    return 0;
+}
+
 /* ------------------------------------------------------------------ */
 /* graph induction + GFA                                                */
 /* ------------------------------------------------------------------ */

@@ -189,6 +189,14 @@ int64_t sro_align_and_unite(sro_seqrush *s, const sro_params *p,
                             uint64_t pair_begin, uint64_t pair_end,
                             uint64_t *dp_cells);
 
+/* the same over an explicit ordered pair list */
+int64_t sro_align_and_unite_list(sro_seqrush *s, const sro_params *p, const uint32_t *pq, const uint32_t *pt,
+                                 uint64_t count, uint64_t *dp_cells);
+/* sparsified ordered pair list (own definition, see seqrush.c; PARITY UNPINNED: allwave's rules are absent).
+ * Arrays are malloc'd (free()). */
+int sro_sparsified_pairs(const sro_seqrush *s, const sro_sparsification *sp, uint64_t seed, int exclude_self,
+                         uint32_t **pq_out, uint32_t **pt_out, uint64_t *count);
+
 /* ---------------- graph induction + GFA (consumer, A9) ---------------- */
 /* build_bidirected_graph_with_options bidirected_builder.rs:17-289 +
  * write_gfa bidirected_ops.rs:880-925, --no-sort --no-compact.

@@ -21,7 +21,9 @@ EXPORTS = [
     "sr_ctx_num_pairs", "sr_ctx_dp_cells", "sr_ctx_labels_device", "sr_ctx_merge_labels",
     "sr_ctx_download_labels", "sr_ctx_kernel_ms", "sr_ctx_counters", "sr_build_gfa", "sr_free",
     "sr_last_error", "sr_abi_version", "sr_device_count", "sr_pair_list", "sr_ctx_align_kernel",
-    "sr_ctx_load_paf", "sr_unite_paf", "sr_ctx_build_gfa",
+    "sr_ctx_load_paf", "sr_unite_paf", "sr_ctx_build_gfa", "sr_ctx_load_pairs", "sr_ctx_pairs",
+    "sr_ctx_num_batches", "sr_ctx_workspace_report", "sr_ctx_run", "sr_ctx_align_all", "sr_ctx_pair_results",
+    "sr_ctx_labels_device_u32", "sr_ctx_merge_labels_u32", "sr_ctx_counters_ext",
 ]
 
 
@@ -42,6 +44,8 @@ class ParamsC(C.Structure):
         ("sparsify_kind", C.c_int32), ("sparsify_factor", C.c_double),
         ("sparsify_seed", C.c_uint64), ("canonical_labels", C.c_int32), ("device", C.c_int32),
         ("shard_rank", C.c_uint32), ("shard_count", C.c_uint32),
+        ("tree_k_nearest", C.c_uint32), ("tree_k_farthest", C.c_uint32), ("tree_rand_frac", C.c_double),
+        ("tree_kmer", C.c_uint32),
     ]
 
 
@@ -107,6 +111,16 @@ def load():
     L.sr_unite_paf.argtypes = [PS, PP, C.c_char_p, C.POINTER(u64)]
     L.sr_ctx_build_gfa.argtypes = [vp, PS, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
     L.sr_ctx_counters.argtypes = [vp, C.POINTER(u64)]
+    L.sr_ctx_counters_ext.argtypes = [vp, C.POINTER(u64)]
+    L.sr_ctx_load_pairs.argtypes = [vp, PS, PP, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), u64]
+    L.sr_ctx_pairs.argtypes = [vp, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(u64)]
+    L.sr_ctx_num_batches.argtypes = [vp]; L.sr_ctx_num_batches.restype = C.c_uint32
+    L.sr_ctx_workspace_report.argtypes = [vp]; L.sr_ctx_workspace_report.restype = C.c_char_p
+    L.sr_ctx_run.argtypes = [vp]
+    L.sr_ctx_align_all.argtypes = [vp, i32, C.POINTER(C.POINTER(AlignmentsC))]
+    L.sr_ctx_pair_results.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint8), C.POINTER(C.c_uint32)]
+    L.sr_ctx_labels_device_u32.argtypes = [vp, vp]
+    L.sr_ctx_merge_labels_u32.argtypes = [vp, vp, C.c_uint32]
     L.sr_build_gfa.argtypes = [PS, C.POINTER(u64), C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
     L.sr_pair_list.argtypes = [C.c_uint32, PP, C.POINTER(C.POINTER(C.c_uint32)),
                                C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(u64)]

@@ -104,16 +104,18 @@ int main(int argc, char **argv) {
         printf("Reading alignments from PAF file: %s\n", paf_in.c_str());
         if (sr_ctx_load_paf(ctx, &set, &p, paf_in.c_str())) return die();
     } else {
-        if (sr_ctx_load(ctx, &set, &p) || sr_ctx_align(ctx)) return die();
-        if (!paf_out.empty()) {                              // --output-alignments (src/seqrush.rs:678-716)
-            sr_alignments *al = nullptr;
-            if (sr_ctx_alignments(ctx, &al)) return die();
-            printf("Writing alignments to %s\n", paf_out.c_str());
-            if (sr_write_paf(al, &set, paf_out.c_str())) { sr_alignments_free(al); return die(); }
-            sr_alignments_free(al);
-        }
+        if (sr_ctx_load(ctx, &set, &p)) return die();
     }
-    if (sr_ctx_unite(ctx) || sr_ctx_sync(ctx)) return die();
+    if (!paf_in.empty() || paf_out.empty()) {
+        if (sr_ctx_run(ctx)) return die();                   // align + unite, batch after batch (PAF input: unite only)
+    } else {                                                 // --output-alignments (src/seqrush.rs:678-716)
+        sr_alignments *al = nullptr;
+        if (sr_ctx_align_all(ctx, 1, &al)) return die();
+        printf("Writing alignments to %s\n", paf_out.c_str());
+        if (sr_write_paf(al, &set, paf_out.c_str())) { sr_alignments_free(al); return die(); }
+        sr_alignments_free(al);
+    }
+    if (sr_ctx_sync(ctx)) return die();
     char *gfa = nullptr;
     uint64_t nn = 0, ne = 0;
     if (sr_ctx_build_gfa(ctx, &set, &gfa, &nn, &ne)) return die();

@@ -1,6 +1,9 @@
 // sr_align_bfs.hip -- translation unit of the level-synchronous biWFA kernel (see sr_align_bfs.inc)
 #include "sr_dev_common.h"
+namespace SR_NS {
 #include "sr_align_bfs.inc"
+}  // namespace
+using namespace SR_NS;
 
 template <typename OT, int NT, bool TWO>
 static int launch_bfs3(const SrAlignArgs *a, int nwg, size_t lds_bytes, hipStream_t st) {
@@ -17,7 +20,7 @@ static int launch_bfs(const SrAlignArgs *a, int nwg, size_t lds_bytes, hipStream
     return a->pen.two ? launch_bfs3<OT, NT, true>(a, nwg, lds_bytes, st)
                       : launch_bfs3<OT, NT, false>(a, nwg, lds_bytes, st);
 }
-extern "C" int srk_align_bfs(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, int nthreads, void *stream) {
+extern "C" int SRK_NAME(srk_align_bfs)(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, int nthreads, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     if (off16) {
         if (nthreads == 128) return launch_bfs<int16_t, 128>(a, nwg, lds_bytes, st);

@@ -268,13 +268,13 @@ __device__ __forceinline__ void group_finish(const StepRows<OT> &r, int g, const
         if (mv[j] >= 0) {
             if (nn[j] > 0) {
                 int c;
-                if (!r.rev) c = xw[j] ? ((__ffs((int)xw[j]) - 1) >> 1) : 16;
-                else c = xw[j] ? (__clz((int)xw[j]) >> 1) : 16;
+                if (!r.rev) c = xw[j] ? ((__ffs((int)xw[j]) - 1) >> SR_SYM_LOG) : SR_WIN;
+                else c = xw[j] ? (__clz((int)xw[j]) >> SR_SYM_LOG) : SR_WIN;
                 c = min(c, nn[j]);
-                if (xw[j] == 0 && nn[j] > 16) {
-                    const int v = mv[j] - k + 16, h = mv[j] + 16;
-                    if (!r.rev) c += ext_fwd(P, T, r.pb + v, r.tb + h, nn[j] - 16);
-                    else c += ext_rev(P, T, r.pe - 1 - v, r.te - 1 - h, nn[j] - 16);
+                if (xw[j] == 0 && nn[j] > SR_WIN) {
+                    const int v = mv[j] - k + SR_WIN, h = mv[j] + SR_WIN;
+                    if (!r.rev) c += ext_fwd(P, T, r.pb + v, r.tb + h, nn[j] - SR_WIN);
+                    else c += ext_rev(P, T, r.pe - 1 - v, r.te - 1 - h, nn[j] - SR_WIN);
                 }
                 mv[j] += c;
             }
@@ -754,11 +754,12 @@ __global__ void __launch_bounds__(NT, SR_MIN_WAVES) sr_align_kernel(SrAlignArgs 
             for (int i = 0; i < 3; i++) { g_sh.red_maxak[i][0] = g_sh.red_maxak[i][1] = 0; g_sh.reached[i][0] = g_sh.reached[i][1] = 0; }
         }
         __syncthreads();
-        const int pair = RFL(g_sh.pair);
+        int pair = RFL(g_sh.pair);
         if (pair >= (int)a.npairs) break;
+        if (a.order) pair = (int)a.order[pair];
         const uint32_t q = a.pair_q[pair], t = a.pair_t[pair];
         const int plen = (int)a.seqlen[q], tlen = (int)a.seqlen[t];
-        const int pw = ((plen + 15) >> 4) + 2, tw = ((tlen + 15) >> 4) + 2;
+        const int pw = SR_SEQ_WORDS(plen), tw = SR_SEQ_WORDS(tlen);
         uint32_t *Pf = lds_seq, *Pr = lds_seq + a.max_words, *Tt = lds_seq + 2 * (size_t)a.max_words;
         load_seq_lds<NT>(Pf, (GP<const uint32_t>)a.seqwords + a.word_off_fwd[q] - 1, pw);
         load_seq_lds<NT>(Pr, (GP<const uint32_t>)a.seqwords + a.word_off_rc[q] - 1, pw);

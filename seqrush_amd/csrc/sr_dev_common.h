@@ -5,6 +5,36 @@
 #include "sr_internal.h"
 
 #define NULLV SR_NULL_OFF
+// Symbol width of the packed sequence buffer: 2 bits (inputs over upper-case ACGT), 4 bits (<= 16 distinct
+// bytes, e.g. ACGTN + soft-masked lower case) or 8 bits (raw bytes).  The reference compares raw bytes
+// (src/seqrush.rs:1162-1176, 1268-1283), so the host maps bytes to codes injectively and every kernel
+// translation unit is compiled once per width (-DSR_SYMBITS=N, namespace sr_sN).
+#ifndef SR_SYMBITS
+#define SR_SYMBITS 2
+#endif
+#if SR_SYMBITS == 2
+#define SR_SYM_LOG 1
+#define SR_WIN 16
+#define SR_WIN_LOG 4
+#define SR_NS sr_s2
+#define SRK_NAME(x) x##_s2
+#elif SR_SYMBITS == 4
+#define SR_SYM_LOG 2
+#define SR_WIN 8
+#define SR_WIN_LOG 3
+#define SR_NS sr_s4
+#define SRK_NAME(x) x##_s4
+#elif SR_SYMBITS == 8
+#define SR_SYM_LOG 3
+#define SR_WIN 4
+#define SR_WIN_LOG 2
+#define SR_NS sr_s8
+#define SRK_NAME(x) x##_s8
+#else
+#error "SR_SYMBITS must be 2, 4 or 8"
+#endif
+// words of one packed sequence copy incl. its two pad words
+#define SR_SEQ_WORDS(len) ((((len) + SR_WIN - 1) >> SR_WIN_LOG) + 2)
 #ifndef SR_MIN_WAVES
 #define SR_MIN_WAVES 4
 #endif
@@ -45,15 +75,15 @@ __device__ __forceinline__ int wave_max(int v) {
     return v;
 }
 
-// 16 bases starting at base i (2 bits each, base i in the low bits)
+// SR_WIN symbols starting at symbol i (SR_SYMBITS bits each, symbol i in the low bits)
 __device__ __forceinline__ uint32_t win_fwd(LP w, int i) {
-    const int wi = i >> 4, sh = (i & 15) << 1;
+    const int wi = i >> SR_WIN_LOG, sh = (i & (SR_WIN - 1)) << SR_SYM_LOG;
     const uint64_t v = ((uint64_t)w[wi + 1] << 32) | (uint64_t)w[wi];
     return (uint32_t)(v >> sh);
 }
-// 16 bases ending at base i (base i in the high bits)
+// SR_WIN symbols ending at symbol i (symbol i in the high bits)
 __device__ __forceinline__ uint32_t win_rev(LP w, int i) {
-    return win_fwd(w, i - 15);
+    return win_fwd(w, i - (SR_WIN - 1));
 }
 
 // number of equal bases walking forward from (pi, ti), at most n
@@ -61,7 +91,7 @@ __device__ __forceinline__ int ext_fwd(LP P, LP T, int pi, int ti, int n) {
     int tot = 0;
     while (tot < n) {
         const uint32_t x = win_fwd(P, pi + tot) ^ win_fwd(T, ti + tot);
-        int c = x ? ((__ffs((int)x) - 1) >> 1) : 16;
+        int c = x ? ((__ffs((int)x) - 1) >> SR_SYM_LOG) : SR_WIN;
         c = min(c, n - tot);
         tot += c;
         if (x) break;
@@ -73,7 +103,7 @@ __device__ __forceinline__ int ext_rev(LP P, LP T, int pi, int ti, int n) {
     int tot = 0;
     while (tot < n) {
         const uint32_t x = win_rev(P, pi - tot) ^ win_rev(T, ti - tot);
-        int c = x ? (__clz((int)x) >> 1) : 16;
+        int c = x ? (__clz((int)x) >> SR_SYM_LOG) : SR_WIN;
         c = min(c, n - tot);
         tot += c;
         if (x) break;

@@ -6,6 +6,8 @@
 #include <hip/hip_runtime_api.h>
 #include <algorithm>
 #include <climits>
+#include <functional>
+#include <queue>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -45,6 +47,7 @@ extern "C" void sr_default_params(sr_params *p) {
     p->memory_mode = SR_MEM_ULTRALOW; p->sparsify_kind = SR_SPARSE_NONE; p->sparsify_factor = 1.0;
     p->sparsify_seed = 42; p->canonical_labels = 0; p->device = 0;
     p->shard_rank = 0; p->shard_count = 1;
+    p->tree_k_nearest = 0; p->tree_k_farthest = 0; p->tree_rand_frac = 0.0; p->tree_kmer = 16;
 }
 
 static bool parse_i32(const std::string &s, int32_t *out) {     // Rust str::parse::<i32>
@@ -122,14 +125,33 @@ extern "C" int sr_parse_sparsification(const char *cs, sr_params *p) {      // :
         if (f > 0.0 && f <= 1.0) { p->sparsify_kind = SR_SPARSE_CONNECTIVITY; p->sparsify_factor = f; return SR_OK; }
         return fail(SR_ERR_INVALID, "Connectivity probability must be in (0.0, 1.0]");
     }
-    if (s.rfind("tree:", 0) == 0) {
+    if (s.rfind("tree:", 0) == 0) {                              // tree:neighbor[,stranger[,random[,k-mer]]] (:378-418)
         auto parts = split(s.substr(5), ',');
-        if (parts.empty() || parts.size() > 4) return fail(SR_ERR_INVALID, "Tree sampling requires 1-4 values");
-        for (size_t i = 0; i < parts.size(); i++) {
-            double d;
-            if (!parse_f64(parts[i], &d)) return fail(SR_ERR_INVALID, "Invalid tree parameter: " + parts[i]);
+        if (parts.empty() || parts.size() > 4)
+            return fail(SR_ERR_INVALID, "Tree sampling requires 1-4 values: tree:neighbor[,stranger[,random[,k-mer]]], got " + s);
+        auto parse_usize = [](const std::string &t, uint64_t *v) {      // Rust str::parse::<usize>
+            size_t i = (!t.empty() && t[0] == '+') ? 1 : 0;
+            if (i >= t.size() || t.size() > 19) return false;
+            *v = 0;
+            for (; i < t.size(); i++) { if (t[i] < '0' || t[i] > '9') return false; *v = *v * 10 + (uint64_t)(t[i] - '0'); }
+            return true;
+        };
+        uint64_t kn = 0, kf = 0, km = 16;
+        double rf = 0.0;
+        if (!parse_usize(parts[0], &kn)) return fail(SR_ERR_INVALID, "Invalid neighbor count: " + parts[0]);
+        if (parts.size() >= 2 && !parse_usize(parts[1], &kf)) return fail(SR_ERR_INVALID, "Invalid stranger count: " + parts[1]);
+        if (parts.size() >= 3) {
+            if (!parse_f64(parts[2], &rf)) return fail(SR_ERR_INVALID, "Invalid random fraction: " + parts[2]);
+            if (rf < 0.0 || rf > 1.0) return fail(SR_ERR_INVALID, "Random fraction must be in [0.0, 1.0], got " + parts[2]);
+        }
+        if (parts.size() >= 4) {
+            if (!parse_usize(parts[3], &km)) return fail(SR_ERR_INVALID, "Invalid k-mer size: " + parts[3]);
+            if (km == 0) return fail(SR_ERR_INVALID, "K-mer size must be > 0");
         }
         p->sparsify_kind = SR_SPARSE_TREE;
+        p->tree_k_nearest = (uint32_t)std::min<uint64_t>(kn, 0xffffffffULL);
+        p->tree_k_farthest = (uint32_t)std::min<uint64_t>(kf, 0xffffffffULL);
+        p->tree_rand_frac = rf; p->tree_kmer = (uint32_t)std::min<uint64_t>(km, 0xffffffffULL);
         return SR_OK;
     }
     if (parse_f64(s, &f) && f > 0.0 && f <= 1.0) { p->sparsify_kind = SR_SPARSE_RANDOM; p->sparsify_factor = f; return SR_OK; }
@@ -155,10 +177,12 @@ struct sr_ctx {
     std::vector<uint32_t> len;
     std::vector<uint64_t> goff;
     uint64_t total_len = 0, uf_size = 0;
-    std::vector<uint32_t> pair_q, pair_t;
-    std::vector<uint64_t> cigar_base;
+    std::vector<uint32_t> pair_q, pair_t;          // this rank's pairs, in enumeration order
+    std::vector<uint64_t> cigar_base;              // [np + 1] prefix sums of the per-pair CIGAR reserve (ops)
+    std::vector<uint32_t> batch_first;             // [nbatch + 1]: pair ranges that share the CIGAR arena one after the other
+    uint64_t total_pairs_all_ranks = 0;            // size of the (sparsified) list before sharding
     uint64_t dp_cells = 0;
-    int off16 = 1, nwg = 0, nthreads = 256;
+    int off16 = 1, nwg = 0, nthreads = 256, symbits = 2;
     size_t lds_bytes = 0;
     SrAlignArgs aa{};
     SrUniteArgs ua{};
@@ -166,18 +190,28 @@ struct sr_ctx {
     unsigned long long *d_nodes = nullptr, *d_minarr = nullptr, *d_labels = nullptr;
     unsigned long long *d_counters = nullptr;
     int *d_error = nullptr;
-    uint32_t *d_queue = nullptr, *d_oqueue = nullptr;
+    uint32_t *d_queue = nullptr, *d_oqueue = nullptr, *d_order = nullptr;
+    uint64_t *d_cbase = nullptr;                   // [np + nbatch]: batch b starts at batch_first[b] + b, values relative to its arena
+    uint8_t *d_bases = nullptr;                    // raw bytes of all sequences (sketching, graph induction)
     int onwg = 0;                      // workgroups (= waves) of the orientation kernel, 0 = orientation inside the alignment kernel
     size_t olds_bytes = 0;
     int32_t *d_max_score = nullptr;
-    hipEvent_t ev[5][2]{};
-    bool ev_valid[5] = {false, false, false, false, false};
+    // kernel timing: [kind] -> one event pair per batch (kinds: 0 align, 1 unite, 4 orientation) or a single pair (2, 3)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[5];
+    int ev_used[5] = {0, 0, 0, 0, 0};
     bool loaded = false;
     bool from_paf = false;             // loaded by sr_ctx_load_paf: no alignment stage, no sr_alignments
+    bool aligned_batch_valid = false;  // the arena holds the CIGARs of the last batch sr_ctx_align ran
+    std::string workspace_report;      // sizing of the last load (sr_ctx_workspace_report)
 };
 
 static int dev_alloc(sr_ctx *c, void **p, size_t bytes) {
-    HIPCHK(hipMalloc(p, bytes ? bytes : 16));
+    hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+    if (e != hipSuccess) {
+        char buf[160];
+        snprintf(buf, sizeof(buf), "hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+        return fail(e == hipErrorOutOfMemory ? SR_ERR_NOMEM : SR_ERR_HIP, buf);
+    }
     c->dev_allocs.push_back(*p);
     return SR_OK;
 }
@@ -185,8 +219,21 @@ static void free_dev(sr_ctx *c) {
     for (void *p : c->dev_allocs) (void)hipFree(p);
     c->dev_allocs.clear();
     c->d_nodes = c->d_minarr = c->d_labels = c->d_counters = nullptr;
-    c->d_error = nullptr; c->d_queue = nullptr; c->d_oqueue = nullptr; c->d_max_score = nullptr; c->onwg = 0;
-    c->loaded = false; c->from_paf = false;
+    c->d_error = nullptr; c->d_queue = nullptr; c->d_oqueue = nullptr; c->d_order = nullptr; c->d_cbase = nullptr;
+    c->d_bases = nullptr; c->d_max_score = nullptr; c->onwg = 0;
+    c->loaded = false; c->from_paf = false; c->aligned_batch_valid = false;
+    for (int k = 0; k < 5; k++) c->ev_used[k] = 0;
+}
+
+// event pair `idx` of kind `kind` (created on first use)
+static int ev_get(sr_ctx *c, int kind, int idx, hipEvent_t **a, hipEvent_t **b) {
+    while ((int)c->ev[kind].size() <= idx) {
+        hipEvent_t x = nullptr, y = nullptr;
+        HIPCHK(hipEventCreate(&x)); HIPCHK(hipEventCreate(&y));
+        c->ev[kind].push_back({x, y});
+    }
+    *a = &c->ev[kind][idx].first; *b = &c->ev[kind][idx].second;
+    return SR_OK;
 }
 
 extern "C" int sr_ctx_create(int device, sr_ctx **out) {
@@ -199,9 +246,6 @@ extern "C" int sr_ctx_create(int device, sr_ctx **out) {
     c->device = device;
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return fail(SR_ERR_HIP, "hipStreamCreate failed"); }
     c->own_stream = true;
-    for (int i = 0; i < 5; i++)
-        for (int j = 0; j < 2; j++)
-            if (hipEventCreate(&c->ev[i][j]) != hipSuccess) { delete c; return fail(SR_ERR_HIP, "hipEventCreate failed"); }
     *out = c;
     return SR_OK;
 }
@@ -211,7 +255,8 @@ extern "C" void sr_ctx_destroy(sr_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     free_dev(c);
-    for (int i = 0; i < 5; i++) for (int j = 0; j < 2; j++) if (c->ev[i][j]) (void)hipEventDestroy(c->ev[i][j]);
+    for (int k = 0; k < 5; k++)
+        for (auto &e : c->ev[k]) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -224,9 +269,6 @@ extern "C" int sr_ctx_set_stream(sr_ctx *c, void *hip_stream) {
     return SR_OK;
 }
 
-static inline int code2(uint8_t b) {
-    switch (b) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return -1; }
-}
 static inline uint8_t comp_base(uint8_t b) {      // Sequence::reverse_complement seqrush.rs:281-295
     switch (b) {
     case 'A': case 'a': return 'T'; case 'T': case 't': return 'A';
@@ -241,36 +283,91 @@ static uint64_t splitmix64(uint64_t x) {
     x = (x ^ (x >> 27)) * 0x94d049bb133111ebULL;
     return x ^ (x >> 31);
 }
+static inline double unit53(uint64_t h) { return (double)(h >> 11) * (1.0 / 9007199254740992.0); }
 
+// ------------------------------------------------------------------ pair list (A2)
+// Ordered pair list before sharding: row-major n*n incl. self pairs ("all-vs-all including self",
+// seqrush.rs:718-734), optional exclude_self, then the sparsification strategy (grammar seqrush.rs:356-431).
+// allwave's selection rules are not in the reference tree; the definitions below are this project's own
+// (restated in oracle/seqrush.c, PARITY UNPINNED):
+//   random:F        ordered pair (q,t), q != t, kept iff unit(splitmix64(seed ^ (q*n+t))) < F
+//   connectivity:P  unordered pair {i<j} kept iff unit(splitmix64(seed ^ (i*n+j))) < f,
+//                   f = min(1, (ln n + c) / n), c = -ln(-ln P): the Erdos-Renyi threshold at which G(n,f) is
+//                   connected with probability P (P = 1 or n <= 2: f = 1); both directions of a kept pair are aligned
+//   auto            n < 10: none; else connectivity:0.99
+//   tree:kn,kf,rf,k unordered pair kept iff it is one of the kn nearest or kf farthest neighbours of either end by
+//                   k-mer sketch similarity (sr_sketch.hip), or unit(splitmix64(seed ^ (i*n+j))) < rf
+// Self pairs are always kept unless exclude_self.
+static double connectivity_fraction(uint32_t n, double P) {
+    if (n <= 2 || P >= 1.0) return 1.0;
+    const double c = -std::log(-std::log(P));
+    const double f = (std::log((double)n) + c) / (double)n;
+    return f >= 1.0 ? 1.0 : (f <= 0.0 ? 0.0 : f);
+}
 
-// Ordered pair list of this rank: row-major n*n incl. self pairs ("all-vs-all
-// including self", seqrush.rs:718-734), optional exclude_self, random:F
-// sparsification (own definition: keep ordered pair (q,t), q != t, iff
-// splitmix64(seed ^ (q*n+t)) / 2^53 < F; allwave's rule is not in the
-// reference tree), then interleaved sharding: kept pair number j belongs to
-// rank j % shard_count.
-static void build_pair_list(uint32_t n, const sr_params &p, std::vector<uint32_t> &pq, std::vector<uint32_t> &pt) {
+// sel: n*n bytes from the device k-NN selection (tree), or NULL
+static void enumerate_pairs(uint32_t n, const sr_params &p, const uint8_t *sel, std::vector<uint32_t> &pq, std::vector<uint32_t> &pt) {
     pq.clear(); pt.clear();
-    uint64_t kept = 0;
+    int kind = p.sparsify_kind;
+    double frac = p.sparsify_factor;
+    if (kind == SR_SPARSE_AUTO) { if (n < 10) kind = SR_SPARSE_NONE; else { kind = SR_SPARSE_CONNECTIVITY; frac = 0.99; } }
+    const double conn_f = (kind == SR_SPARSE_CONNECTIVITY) ? connectivity_fraction(n, frac) : 1.0;
     for (uint32_t q = 0; q < n; q++)
         for (uint32_t t = 0; t < n; t++) {
-            if (p.exclude_self && q == t) continue;
-            if (p.sparsify_kind == SR_SPARSE_RANDOM && q != t) {
-                const uint64_t h = splitmix64(p.sparsify_seed ^ ((uint64_t)q * n + t));
-                if ((double)(h >> 11) * (1.0 / 9007199254740992.0) >= p.sparsify_factor) continue;
-            }
-            if (kept % p.shard_count == p.shard_rank) { pq.push_back(q); pt.push_back(t); }
-            kept++;
+            if (q == t) { if (p.exclude_self) continue; pq.push_back(q); pt.push_back(t); continue; }
+            const uint32_t i = std::min(q, t), j = std::max(q, t);
+            bool keep = true;
+            if (kind == SR_SPARSE_RANDOM)
+                keep = unit53(splitmix64(p.sparsify_seed ^ ((uint64_t)q * n + t))) < frac;
+            else if (kind == SR_SPARSE_CONNECTIVITY)
+                keep = unit53(splitmix64(p.sparsify_seed ^ ((uint64_t)i * n + j))) < conn_f;
+            else if (kind == SR_SPARSE_TREE)
+                keep = (sel && (sel[(uint64_t)i * n + j] || sel[(uint64_t)j * n + i])) ||
+                       unit53(splitmix64(p.sparsify_seed ^ ((uint64_t)i * n + j))) < p.tree_rand_frac;
+            if (keep) { pq.push_back(q); pt.push_back(t); }
         }
+}
+
+// Cost-balanced shard: pairs sorted by cost (|q|*|t|; self pairs cost |q|: they end in one
+// extension), longest first, each handed to the least loaded rank (lowest rank on ties); a rank keeps its pairs
+// in enumeration order.  Every rank computes the same assignment.  Equal costs degenerate to round-robin.
+static void shard_pairs(const std::vector<uint32_t> &len, uint32_t rank, uint32_t count, std::vector<uint32_t> &pq,
+                        std::vector<uint32_t> &pt) {
+    if (count <= 1) return;
+    const size_t m = pq.size();
+    std::vector<uint64_t> cost(m);
+    for (size_t i = 0; i < m; i++)
+        cost[i] = pq[i] == pt[i] ? (uint64_t)len[pq[i]] : (uint64_t)len[pq[i]] * (uint64_t)len[pt[i]];
+    std::vector<uint32_t> idx(m);
+    for (size_t i = 0; i < m; i++) idx[i] = (uint32_t)i;
+    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+    typedef std::pair<uint64_t, uint32_t> LR;           // (load, rank): min-heap
+    std::priority_queue<LR, std::vector<LR>, std::greater<LR>> heap;
+    for (uint32_t r = 0; r < count; r++) heap.push({0, r});
+    std::vector<uint8_t> mine(m, 0);
+    for (uint32_t i : idx) {
+        LR top = heap.top(); heap.pop();
+        if (top.second == rank) mine[i] = 1;
+        top.first += cost[i] ? cost[i] : 1;
+        heap.push(top);
+    }
+    size_t w = 0;
+    for (size_t i = 0; i < m; i++) if (mine[i]) { pq[w] = pq[i]; pt[w] = pt[i]; w++; }
+    pq.resize(w); pt.resize(w);
 }
 
 extern "C" int sr_pair_list(uint32_t n, const sr_params *p, uint32_t **q_out, uint32_t **t_out, uint64_t *count) {
     if (!p || !q_out || !t_out || !count) return fail(SR_ERR_INVALID, "null argument");
     if (p->shard_count == 0 || p->shard_rank >= p->shard_count) return fail(SR_ERR_INVALID, "bad shard");
-    if (p->sparsify_kind != SR_SPARSE_NONE && p->sparsify_kind != SR_SPARSE_RANDOM)
-        return fail(SR_ERR_UNSUPPORTED, "only sparsification none / random:F is implemented");
+    if (p->sparsify_kind == SR_SPARSE_TREE)
+        return fail(SR_ERR_UNSUPPORTED, "tree sparsification needs the sequences (k-mer sketches): load a context and call sr_ctx_pairs");
+    if ((uint64_t)n * n > 0xffffffffULL) return fail(SR_ERR_UNSUPPORTED, "more than 2^32 ordered pairs");
     std::vector<uint32_t> pq, pt;
-    build_pair_list(n, *p, pq, pt);
+    enumerate_pairs(n, *p, nullptr, pq, pt);
+    // sharding by cost needs lengths; this host-only helper assumes equal lengths (= round-robin over the
+    // off-diagonal pairs, then over the cheaper self pairs)
+    std::vector<uint32_t> len(n, 2);
+    shard_pairs(len, p->shard_rank, p->shard_count, pq, pt);
     *count = pq.size();
     *q_out = (uint32_t *)malloc((pq.size() ? pq.size() : 1) * 4);
     *t_out = (uint32_t *)malloc((pt.size() ? pt.size() : 1) * 4);
@@ -285,7 +382,10 @@ static int make_pen(const sr_params &p, bool ori, SrPen *out) {
         out->x = p.ori_mismatch; out->o1 = p.ori_gap_open; out->e1 = p.ori_gap_ext;
         out->o2 = 0; out->e2 = 0; out->two = 0;
     } else {
-        if (p.match_score != 0) return fail(SR_ERR_UNSUPPORTED, "match score must be 0 (WFA2 penalties, seqrush.rs:45)");
+        if (p.match_score != 0)
+            return fail(SR_ERR_UNSUPPORTED, "match score must be 0 (WFA2 penalties, seqrush.rs:45); the Aligner-trait defaults "
+                                            "2,4,4,2,24,1 (src/aligner/allwave_impl.rs:15-23) need allwave's score conversion, "
+                                            "which is not in the reference tree -- see INTEGRATION.md section 8");
         out->x = p.mismatch_penalty; out->o1 = p.gap_open1; out->e1 = p.gap_ext1;
         out->two = p.gap_open2 >= 0;
         out->o2 = out->two ? p.gap_open2 : 0; out->e2 = out->two ? p.gap_ext2 : 0;
@@ -299,7 +399,30 @@ static int make_pen(const sr_params &p, bool ori, SrPen *out) {
     return SR_OK;
 }
 
-extern "C" int sr_ctx_load(sr_ctx *c, const sr_seqset *seqs, const sr_params *p) {
+// ------------------------------------------------------------------ load
+// Symbol codes of the packed buffer.  The reference compares raw bytes (seqrush.rs:1162-1176, 1268-1283), so any
+// injective byte -> code map keeps every comparison: 2 bits when the inputs (and their complements) are within
+// upper-case ACGT, 4 bits for <= 16 distinct bytes (N, IUPAC, soft-masked lower case), else the bytes themselves.
+struct SymMap { int bits; int code[256]; };
+static SymMap make_symmap(const sr_seqset *seqs) {
+    bool present[256] = {false};
+    const uint64_t N = seqs->offsets[seqs->n];
+    for (uint64_t i = 0; i < N; i++) present[seqs->bases[i]] = true;
+    for (int b = 0; b < 256; b++) if (present[b]) present[comp_base((uint8_t)b)] = true;
+    SymMap m;
+    for (int b = 0; b < 256; b++) m.code[b] = -1;
+    bool acgt = true;
+    int distinct = 0;
+    for (int b = 0; b < 256; b++) if (present[b]) { distinct++; if (b != 'A' && b != 'C' && b != 'G' && b != 'T') acgt = false; }
+    if (acgt) { m.bits = 2; m.code['A'] = 0; m.code['C'] = 1; m.code['G'] = 2; m.code['T'] = 3; return m; }
+    if (distinct <= 16) { m.bits = 4; int k = 0; for (int b = 0; b < 256; b++) if (present[b]) m.code[b] = k++; return m; }
+    m.bits = 8;
+    for (int b = 0; b < 256; b++) m.code[b] = b;
+    return m;
+}
+
+static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const uint32_t *eq, const uint32_t *et,
+                     uint64_t ecount, bool explicit_pairs) {
     if (!c || !seqs || !p) return fail(SR_ERR_INVALID, "null argument");
     if (seqs->n == 0) return fail(SR_ERR_INVALID, "no sequences");
     HIPCHK(hipSetDevice(c->device));
@@ -326,43 +449,114 @@ extern "C" int sr_ctx_load(sr_ctx *c, const sr_seqset *seqs, const sr_params *p)
     int r;
     if ((r = make_pen(*p, false, &pen))) return r;
     if ((r = make_pen(*p, true, &ori))) return r;
-    if (p->memory_mode != SR_MEM_ULTRALOW && p->memory_mode != SR_MEM_HIGH)
-        return fail(SR_ERR_UNSUPPORTED, "memory_mode must be SR_MEM_ULTRALOW or SR_MEM_HIGH");
-    if (p->sparsify_kind != SR_SPARSE_NONE && p->sparsify_kind != SR_SPARSE_RANDOM)
-        return fail(SR_ERR_UNSUPPORTED, "only sparsification none / random:F is implemented on device");
+    if (p->memory_mode != SR_MEM_ULTRALOW)
+        return fail(SR_ERR_UNSUPPORTED, "memory_mode must be SR_MEM_ULTRALOW (biWFA, what the reference selects: src/wfa.rs:57); "
+                                        "the device keeps full wavefront history only for biWFA's base cases");
+    if (p->sparsify_kind < SR_SPARSE_NONE || p->sparsify_kind > SR_SPARSE_TREE) return fail(SR_ERR_INVALID, "bad sparsify_kind");
+    if (p->sparsify_kind == SR_SPARSE_TREE && (p->tree_kmer < 1 || p->tree_kmer > 32))
+        return fail(SR_ERR_UNSUPPORTED, "tree sparsification: k-mer size must be in 1..32 on the device");
     if (p->shard_count == 0 || p->shard_rank >= p->shard_count) return fail(SR_ERR_INVALID, "bad shard");
-    // ---- pack 2-bit forward + reverse complement, one pad word either side
-    std::vector<uint64_t> woff_f(n), woff_r(n);
+    if (!explicit_pairs && (uint64_t)n * n > 0xffffffffULL)
+        return fail(SR_ERR_UNSUPPORTED, "more than 2^32 ordered pairs: sparsify (-x) or pass an explicit pair list");
+    void *d;
+    // ---- raw bytes on the device (sketches, graph induction)
+    if ((r = dev_alloc(c, &d, c->total_len))) return r;
+    c->d_bases = (uint8_t *)d;
+    HIPCHK(hipMemcpyAsync(c->d_bases, seqs->bases, c->total_len, hipMemcpyHostToDevice, c->stream));
+    // ---- packed symbol buffer: forward, reverse complement (+ reversed, complemented when the alphabet is not plain
+    //      ACGT: seqrush's complement maps lower case to upper case, so "equal complements <=> equal bases" fails)
+    const SymMap sm = make_symmap(seqs);
+    c->symbits = sm.bits;
+    const int per_word = 32 / sm.bits;
+    const int ncopies = sm.bits == 2 ? 2 : 4;
+    std::vector<uint64_t> woff[4];
+    for (int k = 0; k < 4; k++) woff[k].assign(n, 0);
     uint64_t words = 0;
     for (uint32_t i = 0; i < n; i++) {
-        const uint64_t w = (c->len[i] + 15) / 16;
-        woff_f[i] = words + 1; words += w + 2;
-        woff_r[i] = words + 1; words += w + 2;
+        const uint64_t w = (c->len[i] + per_word - 1) / per_word;
+        for (int k = 0; k < ncopies; k++) { woff[k][i] = words + 1; words += w + 2; }
+        if (ncopies == 2) { woff[2][i] = woff[1][i]; woff[3][i] = woff[0][i]; }      // aliases (see sr_align_blk.inc)
     }
     std::vector<uint32_t> packed(words, 0);
     for (uint32_t i = 0; i < n; i++) {
         const uint8_t *b = seqs->bases + seqs->offsets[i];
         const uint64_t L = c->len[i];
         for (uint64_t j = 0; j < L; j++) {
-            const int cf = code2(b[j]);
-            const int cr = code2(comp_base(b[L - 1 - j]));
-            if (cf < 0 || cr < 0)
-                return fail(SR_ERR_ALPHABET, "sequence byte outside upper-case ACGT: the 2-bit device path cannot "
-                                             "represent it (reference compares raw bytes, seqrush.rs:1269-1283)");
-            packed[woff_f[i] + (j >> 4)] |= (uint32_t)cf << ((j & 15) * 2);
-            packed[woff_r[i] + (j >> 4)] |= (uint32_t)cr << ((j & 15) * 2);
+            const unsigned sh = (unsigned)(j % per_word) * sm.bits;
+            const uint64_t wi = j / per_word;
+            packed[woff[0][i] + wi] |= (uint32_t)sm.code[b[j]] << sh;                          // forward
+            packed[woff[1][i] + wi] |= (uint32_t)sm.code[comp_base(b[L - 1 - j])] << sh;      // reverse complement
+            if (ncopies == 4) {
+                packed[woff[2][i] + wi] |= (uint32_t)sm.code[b[L - 1 - j]] << sh;              // reversed
+                packed[woff[3][i] + wi] |= (uint32_t)sm.code[comp_base(b[j])] << sh;           // complemented
+            }
         }
     }
-    // ---- ordered pair list, row-major incl. self (seqrush.rs:718-734), sparsify, shard
-    build_pair_list(n, *p, c->pair_q, c->pair_t);
-    c->dp_cells = 0;
-    for (size_t i = 0; i < c->pair_q.size(); i++) c->dp_cells += (uint64_t)c->len[c->pair_q[i]] * c->len[c->pair_t[i]];
+    SrAlignArgs &a = c->aa;
+    memset(&a, 0, sizeof(a));
+#define DEV_UPLOAD(field, T, hostvec)                                                         \
+    do {                                                                                      \
+        const auto &hv_ = (hostvec);                                                          \
+        if ((r = dev_alloc(c, &d, hv_.size() * sizeof(T)))) return r;                         \
+        HIPCHK(hipMemcpyAsync(d, hv_.data(), hv_.size() * sizeof(T), hipMemcpyHostToDevice, c->stream)); \
+        field = (T *)d;                                                                       \
+    } while (0)
+    uint32_t *d_words; uint64_t *d_w[4], *d_goff; uint32_t *d_len, *d_pq, *d_pt;
+    DEV_UPLOAD(d_words, uint32_t, packed);
+    DEV_UPLOAD(d_w[0], uint64_t, woff[0]);
+    DEV_UPLOAD(d_w[1], uint64_t, woff[1]);
+    if (ncopies == 4) { DEV_UPLOAD(d_w[2], uint64_t, woff[2]); DEV_UPLOAD(d_w[3], uint64_t, woff[3]); }
+    else { d_w[2] = d_w[1]; d_w[3] = d_w[0]; }
+    DEV_UPLOAD(d_len, uint32_t, c->len);
+    DEV_UPLOAD(d_goff, uint64_t, c->goff);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    // ---- ordered pair list: enumeration / explicit list, sparsification (tree: sketches on the device), shard
+    if (explicit_pairs) {
+        c->pair_q.assign(eq, eq + ecount); c->pair_t.assign(et, et + ecount);
+        for (uint64_t i = 0; i < ecount; i++)
+            if (eq[i] >= n || et[i] >= n) return fail(SR_ERR_INVALID, "pair index out of range");
+    } else {
+        std::vector<uint8_t> sel;
+        if (p->sparsify_kind == SR_SPARSE_TREE && n > 1) {
+            const int S = 1000;
+            std::vector<uint32_t> npad(n);
+            uint64_t stride = 2;
+            for (uint32_t i = 0; i < n; i++) { uint32_t v = 2; while (v < c->len[i]) v <<= 1; npad[i] = v; stride = std::max<uint64_t>(stride, v); }
+            struct Tmp { std::vector<void *> v; ~Tmp() { for (void *q : v) (void)hipFree(q); } } tmp;
+            auto talloc = [&](size_t bytes) -> void * { void *q = nullptr; if (hipMalloc(&q, bytes ? bytes : 16) != hipSuccess) return nullptr; tmp.v.push_back(q); return q; };
+            unsigned long long *d_scr = (unsigned long long *)talloc((size_t)n * stride * 8);
+            unsigned long long *d_sk = (unsigned long long *)talloc((size_t)n * S * 8);
+            uint32_t *d_skn = (uint32_t *)talloc((size_t)n * 4), *d_npad = (uint32_t *)talloc((size_t)n * 4);
+            uint32_t *d_sh = (uint32_t *)talloc((size_t)n * n * 4), *d_dn = (uint32_t *)talloc((size_t)n * n * 4);
+            uint8_t *d_sel = (uint8_t *)talloc((size_t)n * n);
+            if (!d_scr || !d_sk || !d_skn || !d_npad || !d_sh || !d_dn || !d_sel) return fail(SR_ERR_NOMEM, "not enough device memory for the k-mer sketches");
+            HIPCHK(hipMemcpyAsync(d_npad, npad.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipMemsetAsync(d_sel, 0, (size_t)n * n, c->stream));
+            HIPCHK(hipMemsetAsync(d_sh, 0, (size_t)n * n * 4, c->stream));
+            HIPCHK(hipMemsetAsync(d_dn, 0, (size_t)n * n * 4, c->stream));
+            if (srk_sketch(c->d_bases, d_goff, d_len, n, (int)p->tree_kmer, S, d_scr, stride, d_npad, d_sk, d_skn, c->stream) ||
+                srk_jaccard(d_sk, d_skn, n, S, d_sh, d_dn, c->stream) ||
+                srk_knn_select(d_sh, d_dn, n, (int)std::min<uint32_t>(p->tree_k_nearest, n), (int)std::min<uint32_t>(p->tree_k_farthest, n), d_sel, c->stream))
+                return fail(SR_ERR_HIP, "sketch kernel launch failed");
+            sel.resize((size_t)n * n);
+            HIPCHK(hipStreamSynchronize(c->stream));
+            HIPCHK(hipMemcpy(sel.data(), d_sel, (size_t)n * n, hipMemcpyDeviceToHost));
+        }
+        enumerate_pairs(n, *p, sel.empty() ? nullptr : sel.data(), c->pair_q, c->pair_t);
+    }
+    c->total_pairs_all_ranks = c->pair_q.size();
+    shard_pairs(c->len, p->shard_rank, p->shard_count, c->pair_q, c->pair_t);
+    if (c->pair_q.size() > 0xfffffff0ULL) return fail(SR_ERR_UNSUPPORTED, "more than 2^32 pairs in one shard");
     const uint32_t np = (uint32_t)c->pair_q.size();
+    c->dp_cells = 0;
     c->cigar_base.assign((size_t)np + 1, 0);
-    std::vector<int32_t> max_score(np, INT_MAX);
+    std::vector<int32_t> max_score(std::max<uint32_t>(np, 1), INT_MAX);
+    uint64_t max_reserve = 4;
     for (uint32_t i = 0; i < np; i++) {
         const uint64_t lq = c->len[c->pair_q[i]], lt = c->len[c->pair_t[i]];
+        c->dp_cells += lq * lt;
         c->cigar_base[i + 1] = c->cigar_base[i] + lq + lt + 2;
+        max_reserve = std::max(max_reserve, lq + lt + 2);
         if (p->max_divergence >= 0.0) max_score[i] = max_score_for_divergence(*p, std::min(lq, lt), p->max_divergence);
     }
     // ---- geometry
@@ -371,17 +565,19 @@ extern "C" int sr_ctx_load(sr_ctx *c, const sr_seqset *seqs, const sr_params *p)
     const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->off16 = maxlen <= 32000 ? 1 : 0;
     const size_t osz = c->off16 ? 2 : 4;
-    const uint32_t max_words = (uint32_t)((maxlen + 15) / 16 + 2);
+    const uint32_t max_words = (uint32_t)((maxlen + per_word - 1) / per_word + 2);
     c->lds_bytes = (size_t)max_words * 3 * 4;          // query fwd / rc + target fwd
     if ((long long)c->lds_bytes > (long long)srk_align_max_lds())
-        return fail(SR_ERR_UNSUPPORTED, "sequences too long to stage in LDS (limit ~ 200 kb per sequence)");
+        return fail(SR_ERR_UNSUPPORTED, "sequences too long to stage in LDS (limit ~ 200 kb per sequence at 2 bits per base)");
     // implementation: 1 = level-synchronous ("bfs") kernel, 0 = one-segment-at-a-time kernel
     // 2 = score-blocked wave-tiled kernel (when this build has an instance for the penalties)
     int impl = (std::max(pen.scope, ori.scope) + 1 <= 32) ? 1 : 0;
     const int kblock = srk_align_blk_supports(&pen, &ori);
-    // impl 2 also stages the target's reverse complement (4 regions) and has ~36 KB of static LDS
+    // impl 2 also stages the reversed target (4 regions) and has ~16 KB of static LDS
     if (impl && kblock > 0 && (long long)max_words * 16 + 40 * 1024 <= 160 * 1024) impl = 2;
     if (const char *e = getenv("SR_ALIGN_IMPL")) impl = std::min(impl, std::max(0, atoi(e)));
+    if (impl == 0 && sm.bits != 2)
+        return fail(SR_ERR_UNSUPPORTED, "penalties with scope > 31 run on sr_align_kernel, which is built for upper-case ACGT input only");
     if (impl == 2) c->lds_bytes = (size_t)max_words * 4 * 4;
     int wg_per_cu = impl ? 4 : 8;
     if (const char *e = getenv("SR_WG_PER_CU")) wg_per_cu = std::max(1, atoi(e));
@@ -408,8 +604,6 @@ extern "C" int sr_ctx_load(sr_ctx *c, const sr_seqset *seqs, const sr_params *p)
     if (pen.two) rmax = std::max(rmax, smax_base / pen.e2);
     const int hist_w = (2 * (rmax + pen.scope + 2) + 1 + 8 + 32 + 7) & ~7;   // rows hold whole 4-diagonal groups
     const uint64_t hist_wg = (uint64_t)hist_levels * 5 * (uint64_t)hist_w + (uint64_t)hist_w;   // + NULL row
-    size_t free_b = 0, total_b = 0;
-    HIPCHK(hipMemGetInfo(&free_b, &total_b));
     // bfs kernel workspace: shared rows (every aligner owns a sub-range) + batched base-case history
     const int brow = (int)((4 * maxlen + 32 * 64 + 64 + 512 + 7) & ~7ULL);     // per-aligner margins + read slack of the last wave tile
     int kdepth = std::max(pen.scope + std::max(kblock, 1), ori.scope + 1) + 1;
@@ -426,38 +620,68 @@ extern "C" int sr_ctx_load(sr_ctx *c, const sr_seqset *seqs, const sr_params *p)
     const uint64_t bbt_wg = (uint64_t)bbase_jobs * SR_BFS_BTCAP * 4;           // bytes
     // impl 2: every diagonal of every level of a block can be a breakpoint candidate at worst
     const uint64_t bcl_wg = (impl == 2) ? (uint64_t)std::max(kblock, 1) * (uint64_t)brow : 0;
-    const uint64_t per_wg_bytes = impl ? (bring_wg + bhist_wg) * osz + bseg_wg + bbt_wg + bcl_wg * 4 : (ring_wg + hist_wg) * osz;
-    uint64_t budget = (uint64_t)(free_b * 0.6);
+    const uint64_t per_wg_bytes = impl ? (bring_wg + bhist_wg) * osz + bseg_wg + bbt_wg + bcl_wg * 4 + (impl == 2 ? 32 * SR_BLK_MAK_SLOTS * 4 : 0)
+                                       : (ring_wg + hist_wg) * osz;
+    // ---- memory budget: every buffer counted.  fixed = union-find arrays + per-pair arrays;
+    //      then the CIGAR arena (worst case |q|+|t|+2 ops per pair; pairs run in batches that reuse it), the
+    //      orientation rings and the alignment workspaces share what is left.
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    const uint64_t fixed = 3ULL * c->uf_size * 8 + (uint64_t)np * 40 + (1ULL << 20);
+    if (fixed + (64ULL << 20) > free_b) return fail(SR_ERR_NOMEM, "not enough device memory for the union-find arrays");
+    const uint64_t avail = free_b - fixed;
+    uint64_t arena_ops = c->cigar_base[np] + 1;
+    {
+        uint64_t cap = std::max<uint64_t>((uint64_t)(avail * 0.25) / 4, max_reserve + 1);
+        if (const char *e = getenv("SR_CIGAR_ARENA_OPS")) cap = std::max<uint64_t>((uint64_t)atoll(e), max_reserve + 1);   // (tests: force batches)
+        arena_ops = std::min(arena_ops, cap);
+    }
+    if (arena_ops * 4 > avail / 2) return fail(SR_ERR_NOMEM, "not enough device memory for one pair's CIGAR");
+    c->batch_first.assign(1, 0);
+    for (uint32_t i = 0; i < np; i++)
+        if (c->cigar_base[i + 1] - c->cigar_base[c->batch_first.back()] + 1 > arena_ops) c->batch_first.push_back(i);
+    c->batch_first.push_back(np);
+    const uint32_t nbatch = (uint32_t)c->batch_first.size() - 1;
+    uint32_t max_batch_pairs = 0;
+    for (uint32_t b = 0; b < nbatch; b++) max_batch_pairs = std::max(max_batch_pairs, c->batch_first[b + 1] - c->batch_first[b]);
+    const uint64_t left = avail - arena_ops * 4;
+    uint64_t budget = (uint64_t)(left * 0.7);
     int nwg = cus * wg_per_cu;
-    if ((uint64_t)nwg > np) nwg = (int)np;
+    if ((uint64_t)nwg > max_batch_pairs) nwg = (int)max_batch_pairs;
     if (nwg < 1) nwg = 1;
     while (nwg > 1 && (uint64_t)nwg * per_wg_bytes > budget) nwg--;
     if ((uint64_t)nwg * per_wg_bytes > budget) return fail(SR_ERR_NOMEM, "not enough device memory for one workgroup's wavefront ring");
     c->nwg = nwg;
-    // ---- device buffers
-    SrAlignArgs &a = c->aa;
-    memset(&a, 0, sizeof(a));
-    void *d;
-#define DEV_UPLOAD(field, T, hostvec)                                                         \
-    do {                                                                                      \
-        if ((r = dev_alloc(c, &d, (hostvec).size() * sizeof(T)))) return r;                   \
-        HIPCHK(hipMemcpyAsync(d, (hostvec).data(), (hostvec).size() * sizeof(T), hipMemcpyHostToDevice, c->stream)); \
-        field = (T *)d;                                                                       \
-    } while (0)
-    uint32_t *d_words; uint64_t *d_wf, *d_wr, *d_goff, *d_cbase; uint32_t *d_len, *d_pq, *d_pt;
-    DEV_UPLOAD(d_words, uint32_t, packed);
-    DEV_UPLOAD(d_wf, uint64_t, woff_f);
-    DEV_UPLOAD(d_wr, uint64_t, woff_r);
-    DEV_UPLOAD(d_len, uint32_t, c->len);
-    DEV_UPLOAD(d_goff, uint64_t, c->goff);
+    // ---- per-pair device arrays
     std::vector<uint32_t> pq = c->pair_q, pt = c->pair_t;
     if (pq.empty()) { pq.push_back(0); pt.push_back(0); }
     DEV_UPLOAD(d_pq, uint32_t, pq);
     DEV_UPLOAD(d_pt, uint32_t, pt);
-    DEV_UPLOAD(d_cbase, uint64_t, c->cigar_base);
-    DEV_UPLOAD(c->d_max_score, int32_t, max_score.empty() ? std::vector<int32_t>(1, INT_MAX) : max_score);
+    {   // per-batch relative CIGAR bases: batch b owns entries [first_b + b, first_b + b + count_b]
+        std::vector<uint64_t> cb((size_t)np + nbatch, 0);
+        for (uint32_t b = 0; b < nbatch; b++) {
+            const uint32_t f = c->batch_first[b], l = c->batch_first[b + 1];
+            for (uint32_t i = f; i <= l; i++) cb[(size_t)i + b] = c->cigar_base[i] - c->cigar_base[f];
+        }
+        DEV_UPLOAD(c->d_cbase, uint64_t, cb);
+    }
+    {   // cost-sorted dequeue order inside each batch: the longest pairs start first (self pairs last)
+        std::vector<uint32_t> order(std::max<uint32_t>(np, 1), 0);
+        for (uint32_t b = 0; b < nbatch; b++) {
+            const uint32_t f = c->batch_first[b], l = c->batch_first[b + 1];
+            std::vector<uint32_t> idx(l - f);
+            for (uint32_t i = 0; i < l - f; i++) idx[i] = i;
+            auto cost = [&](uint32_t i) { const uint32_t q = c->pair_q[f + i], t = c->pair_t[f + i];
+                                          return q == t ? (uint64_t)c->len[q] : (uint64_t)c->len[q] * c->len[t]; };
+            std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return cost(x) > cost(y); });
+            for (uint32_t i = 0; i < l - f; i++) order[f + i] = idx[i];
+        }
+        DEV_UPLOAD(c->d_order, uint32_t, order);
+    }
+    DEV_UPLOAD(c->d_max_score, int32_t, max_score);
     HIPCHK(hipStreamSynchronize(c->stream));   // host vectors go out of scope
     if ((r = dev_alloc(c, &d, sizeof(uint32_t)))) return r; c->d_queue = (uint32_t *)d;
+    uint64_t oring_bytes = 0;
     if (impl) {
         if ((r = dev_alloc(c, &d, (uint64_t)nwg * bring_wg * osz))) return r; a.bring = d;
         if ((r = dev_alloc(c, &d, (uint64_t)nwg * bhist_wg * osz))) return r; a.bhist = d;
@@ -470,10 +694,11 @@ extern "C" int sr_ctx_load(sr_ctx *c, const sr_seqset *seqs, const sr_params *p)
         if (impl == 2 && !(po && atoi(po) == 0) && (size_t)max_words * 12 <= 60 * 1024) {
             const int orow = (int)((2 * ((2 * maxlen + 32) & ~3ULL) + 512 + 7) & ~7ULL);
             const uint64_t oring_wg = ((uint64_t)(ori.scope + 1) * 3 + 1) * (uint64_t)orow + 256;
-            int onwg = (int)std::min<uint64_t>(np, (uint64_t)cus * 16);
-            while (onwg > 1 && (uint64_t)onwg * oring_wg * osz > (uint64_t)(free_b * 0.2)) onwg--;
+            int onwg = (int)std::min<uint64_t>(max_batch_pairs, (uint64_t)cus * 16);
+            while (onwg > 1 && (uint64_t)onwg * oring_wg * osz > (uint64_t)(left * 0.2)) onwg--;
             if (onwg >= 1 && np > 0) {
-                if ((r = dev_alloc(c, &d, (uint64_t)onwg * oring_wg * osz))) return r; a.oring = d;
+                oring_bytes = (uint64_t)onwg * oring_wg * osz;
+                if ((r = dev_alloc(c, &d, oring_bytes))) return r; a.oring = d;
                 if ((r = dev_alloc(c, &d, sizeof(uint32_t)))) return r; c->d_oqueue = (uint32_t *)d;
                 a.oring_wg_stride = oring_wg; a.orow = orow; a.oqueue = c->d_oqueue; a.pre_oriented = 1;
                 c->onwg = onwg; c->olds_bytes = (size_t)max_words * 3 * 4;
@@ -488,36 +713,74 @@ extern "C" int sr_ctx_load(sr_ctx *c, const sr_seqset *seqs, const sr_params *p)
     if ((r = dev_alloc(c, &d, ((size_t)np + 1) * 4))) return r; a.ori_fwd = (int32_t *)d;
     if ((r = dev_alloc(c, &d, ((size_t)np + 1) * 4))) return r; a.ori_rev = (int32_t *)d;
     if ((r = dev_alloc(c, &d, ((size_t)np + 1) * 4))) return r; a.cigar_cnt = (uint32_t *)d;
-    if ((r = dev_alloc(c, &d, (c->cigar_base[np] + 1) * 4))) return r; a.cigar_ops = (uint32_t *)d;
-    if ((r = dev_alloc(c, &d, 16 * sizeof(unsigned long long)))) return r; c->d_counters = (unsigned long long *)d;
+    if ((r = dev_alloc(c, &d, (arena_ops + 1) * 4))) return r; a.cigar_ops = (uint32_t *)d;
+    if ((r = dev_alloc(c, &d, SR_NCOUNTERS * sizeof(unsigned long long)))) return r; c->d_counters = (unsigned long long *)d;
     if ((r = dev_alloc(c, &d, sizeof(int)))) return r; c->d_error = (int *)d;
     if ((r = dev_alloc(c, &d, c->uf_size * 8))) return r; c->d_nodes = (unsigned long long *)d;
     if ((r = dev_alloc(c, &d, c->uf_size * 8))) return r; c->d_minarr = (unsigned long long *)d;
     if ((r = dev_alloc(c, &d, c->uf_size * 8))) return r; c->d_labels = (unsigned long long *)d;
-    HIPCHK(hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream));
+    HIPCHK(hipMemsetAsync(c->d_counters, 0, SR_NCOUNTERS * sizeof(unsigned long long), c->stream));
     HIPCHK(hipMemsetAsync(c->d_error, 0, sizeof(int), c->stream));
     HIPCHK(hipMemsetAsync(a.cigar_cnt, 0, ((size_t)np + 1) * 4, c->stream));
     HIPCHK(hipMemsetAsync(a.score, 0xff, ((size_t)np + 1) * 4, c->stream));
-    a.seqwords = d_words; a.word_off_fwd = d_wf; a.word_off_rc = d_wr; a.seqlen = d_len;
+    a.seqwords = d_words; a.word_off_fwd = d_w[0]; a.word_off_rc = d_w[1]; a.word_off_rev = d_w[2]; a.word_off_cmp = d_w[3];
+    a.symbits = sm.bits; a.order = c->d_order; a.seqlen = d_len;
     a.max_words = max_words; a.pair_q = d_pq; a.pair_t = d_pt; a.npairs = np;
     a.queue_head = c->d_queue; a.pen = pen; a.ori = ori; a.mem_mode = p->memory_mode;
     a.ring_wg_stride = ring_wg; a.ring_dir_stride = ring_dir; a.ring_cap = ring_cap; a.ring_scope = ring_scope; a.ring_hot = ring_hot;
     a.hist_wg_stride = hist_wg; a.hist_w = hist_w; a.hist_levels = hist_levels;
+    { const char *pt_ = getenv("SR_PROFILE_TICKS"); a.profile_ticks = (pt_ && atoi(pt_) != 0) ? 1 : 0; }
     a.impl = impl; a.kdepth = kdepth; a.lazy_id = lazy_id; a.bring_wg_stride = bring_wg; a.brow = brow; a.bhist_wg_stride = bhist_wg; a.bbase_jobs = bbase_jobs;
-    a.cigar_base = d_cbase; a.counters = c->d_counters; a.error_flag = c->d_error;
+    a.cigar_base = c->d_cbase; a.counters = c->d_counters; a.error_flag = c->d_error;
     SrUniteArgs &u = c->ua;
     memset(&u, 0, sizeof(u));
     u.pair_q = d_pq; u.pair_t = d_pt; u.npairs = np; u.seqlen = d_len; u.seq_goff = d_goff;
     u.is_reverse = a.is_reverse; u.score = a.score; u.max_score = c->d_max_score;
-    u.cigar_ops = a.cigar_ops; u.cigar_base = d_cbase; u.cigar_cnt = a.cigar_cnt;
+    u.cigar_ops = a.cigar_ops; u.cigar_base = c->d_cbase; u.cigar_cnt = a.cigar_cnt;
     u.min_match_len = p->min_match_len; u.nodes = c->d_nodes; u.uf_size = c->uf_size;
     u.counters = c->d_counters; u.error_flag = c->d_error;
+    {
+        char buf[640];
+        snprintf(buf, sizeof(buf),
+                 "{\"pairs\": %u, \"batches\": %u, \"symbol_bits\": %d, \"offset_bytes\": %zu, \"kernel_impl\": %d, \"workgroups\": %d, "
+                 "\"threads_per_workgroup\": %d, \"workgroups_per_cu\": %d, \"lds_dynamic_bytes\": %zu, \"ring_bytes_per_workgroup\": %llu, "
+                 "\"base_history_bytes_per_workgroup\": %llu, \"workspace_bytes\": %llu, \"cigar_arena_bytes\": %llu, "
+                 "\"orientation_ring_bytes\": %llu, \"union_find_bytes\": %llu, \"device_free_bytes_at_load\": %zu}",
+                 np, nbatch, sm.bits, osz, impl, nwg, c->nthreads, wg_per_cu, c->lds_bytes,
+                 (unsigned long long)((impl ? bring_wg : ring_wg) * osz), (unsigned long long)((impl ? bhist_wg : hist_wg) * osz),
+                 (unsigned long long)((uint64_t)nwg * per_wg_bytes), (unsigned long long)(arena_ops * 4), (unsigned long long)oring_bytes,
+                 (unsigned long long)(3ULL * c->uf_size * 8), free_b);
+        c->workspace_report = buf;
+    }
     int rr = srk_uf_init(c->d_nodes, c->total_len, c->uf_size, c->stream);
     if (rr) return fail(SR_ERR_HIP, "uf init launch failed");
     HIPCHK(hipStreamSynchronize(c->stream));
     c->loaded = true;
     return SR_OK;
+#undef DEV_UPLOAD
 }
+
+extern "C" int sr_ctx_load(sr_ctx *c, const sr_seqset *seqs, const sr_params *p) {
+    return load_impl(c, seqs, p, nullptr, nullptr, 0, false);
+}
+extern "C" int sr_ctx_load_pairs(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const uint32_t *query_idx,
+                                 const uint32_t *target_idx, uint64_t count) {
+    if (count && (!query_idx || !target_idx)) return fail(SR_ERR_INVALID, "null pair list");
+    return load_impl(c, seqs, p, query_idx, target_idx, count, true);
+}
+
+extern "C" int sr_ctx_pairs(const sr_ctx *c, uint32_t **q_out, uint32_t **t_out, uint64_t *count) {
+    if (!c || !c->loaded || !q_out || !t_out || !count) return fail(SR_ERR_INVALID, "context not loaded");
+    const size_t m = c->pair_q.size();
+    *count = m;
+    *q_out = (uint32_t *)malloc((m ? m : 1) * 4);
+    *t_out = (uint32_t *)malloc((m ? m : 1) * 4);
+    memcpy(*q_out, c->pair_q.data(), m * 4);
+    memcpy(*t_out, c->pair_t.data(), m * 4);
+    return SR_OK;
+}
+extern "C" uint32_t sr_ctx_num_batches(const sr_ctx *c) { return (c && c->loaded) ? (uint32_t)c->batch_first.size() - 1 : 0; }
+extern "C" const char *sr_ctx_workspace_report(const sr_ctx *c) { return c ? c->workspace_report.c_str() : ""; }
 
 extern "C" int sr_ctx_reset_uf(sr_ctx *c) {
     if (!c || !c->loaded) return fail(SR_ERR_INVALID, "context not loaded");
@@ -526,40 +789,108 @@ extern "C" int sr_ctx_reset_uf(sr_ctx *c) {
     return SR_OK;
 }
 
-extern "C" int sr_ctx_align(sr_ctx *c) {
-    if (!c || !c->loaded) return fail(SR_ERR_INVALID, "context not loaded");
-    HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipMemsetAsync(c->d_queue, 0, sizeof(uint32_t), c->stream));
-    HIPCHK(hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream));
-    if (c->onwg > 0 && c->aa.npairs > 0) {           // which = 4: the orientation kernel
-        HIPCHK(hipMemsetAsync(c->d_oqueue, 0, sizeof(uint32_t), c->stream));
-        HIPCHK(hipEventRecord(c->ev[4][0], c->stream));
-        int r = srk_orient(&c->aa, c->onwg, c->olds_bytes, c->off16, c->stream);
-        if (r) return fail(SR_ERR_HIP, std::string("orientation kernel launch failed: ") + hipGetErrorString((hipError_t)r));
-        HIPCHK(hipEventRecord(c->ev[4][1], c->stream));
-        c->ev_valid[4] = true;
+// kernel arguments of batch b: the per-pair arrays shifted to the batch, its slice of d_cbase
+static void batch_args(const sr_ctx *c, uint32_t b, SrAlignArgs *a, SrUniteArgs *u) {
+    const uint32_t f = c->batch_first[b], cnt = c->batch_first[b + 1] - f;
+    if (a) {
+        *a = c->aa;
+        a->pair_q += f; a->pair_t += f; a->npairs = cnt; if (a->order) a->order += f;
+        a->is_reverse += f; a->score += f; a->ori_fwd += f; a->ori_rev += f; a->cigar_cnt += f;
+        a->cigar_base = c->d_cbase + f + b;
     }
-    HIPCHK(hipEventRecord(c->ev[0][0], c->stream));
-    if (c->aa.npairs > 0) {
-        int r = srk_align(&c->aa, c->nwg, c->lds_bytes, c->off16, c->nthreads, c->stream);
+    if (u) {
+        *u = c->ua;
+        u->pair_q += f; u->pair_t += f; u->npairs = cnt; u->is_reverse += f; u->score += f; u->max_score += f;
+        u->cigar_cnt += f; u->cigar_base = c->d_cbase + f + b;
+        if (u->q_start) { u->q_start += f; u->t_start += f; }
+    }
+}
+
+static int enqueue_align_batch(sr_ctx *c, uint32_t b) {
+    SrAlignArgs a;
+    batch_args(c, b, &a, nullptr);
+    HIPCHK(hipMemsetAsync(c->d_queue, 0, sizeof(uint32_t), c->stream));
+    hipEvent_t *e0, *e1;
+    int r;
+    if (c->onwg > 0 && a.npairs > 0) {           // which = 4: the orientation kernel
+        HIPCHK(hipMemsetAsync(c->d_oqueue, 0, sizeof(uint32_t), c->stream));
+        if ((r = ev_get(c, 4, c->ev_used[4], &e0, &e1))) return r;
+        HIPCHK(hipEventRecord(*e0, c->stream));
+        r = srk_orient(&a, std::min<int>(c->onwg, (int)a.npairs), c->olds_bytes, c->off16, c->stream);
+        if (r) return fail(SR_ERR_HIP, std::string("orientation kernel launch failed: ") + hipGetErrorString((hipError_t)r));
+        HIPCHK(hipEventRecord(*e1, c->stream));
+        c->ev_used[4]++;
+    }
+    if ((r = ev_get(c, 0, c->ev_used[0], &e0, &e1))) return r;
+    HIPCHK(hipEventRecord(*e0, c->stream));
+    if (a.npairs > 0) {
+        r = srk_align(&a, std::min<int>(c->nwg, (int)a.npairs), c->lds_bytes, c->off16, c->nthreads, c->stream);
         if (r) return fail(SR_ERR_HIP, std::string("align kernel launch failed: ") + hipGetErrorString((hipError_t)r));
     }
-    HIPCHK(hipEventRecord(c->ev[0][1], c->stream));
-    c->ev_valid[0] = true;
+    HIPCHK(hipEventRecord(*e1, c->stream));
+    c->ev_used[0]++;
+    return SR_OK;
+}
+
+static int enqueue_unite_batch(sr_ctx *c, uint32_t b) {
+    SrUniteArgs u;
+    batch_args(c, b, nullptr, &u);
+    hipEvent_t *e0, *e1;
+    int r;
+    if ((r = ev_get(c, 1, c->ev_used[1], &e0, &e1))) return r;
+    HIPCHK(hipEventRecord(*e0, c->stream));
+    if (u.npairs > 0) {
+        int nwg = (int)std::min<uint64_t>(u.npairs, 4096);
+        r = srk_unite(&u, nwg, c->stream);
+        if (r) return fail(SR_ERR_HIP, std::string("unite kernel launch failed: ") + hipGetErrorString((hipError_t)r));
+    }
+    HIPCHK(hipEventRecord(*e1, c->stream));
+    c->ev_used[1]++;
+    return SR_OK;
+}
+
+static int begin_pass(sr_ctx *c, bool reset_counters) {
+    HIPCHK(hipSetDevice(c->device));
+    if (reset_counters) {
+        HIPCHK(hipMemsetAsync(c->d_counters, 0, SR_NCOUNTERS * sizeof(unsigned long long), c->stream));
+        c->ev_used[0] = c->ev_used[4] = 0;
+    }
+    return SR_OK;
+}
+
+extern "C" int sr_ctx_align(sr_ctx *c) {
+    if (!c || !c->loaded) return fail(SR_ERR_INVALID, "context not loaded");
+    if (c->from_paf) return fail(SR_ERR_INVALID, "context was loaded from a PAF file: there is no alignment stage");
+    if (c->batch_first.size() > 2)
+        return fail(SR_ERR_UNSUPPORTED, "the pair list runs in several batches that share one CIGAR arena: use sr_ctx_run "
+                                        "(align + unite per batch) or sr_align_all");
+    int r = begin_pass(c, true);
+    if (r) return r;
+    if ((r = enqueue_align_batch(c, 0))) return r;
+    c->aligned_batch_valid = true;
     return SR_OK;
 }
 
 extern "C" int sr_ctx_unite(sr_ctx *c) {
     if (!c || !c->loaded) return fail(SR_ERR_INVALID, "context not loaded");
+    if (c->batch_first.size() > 2) return fail(SR_ERR_UNSUPPORTED, "several batches: use sr_ctx_run");
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipEventRecord(c->ev[1][0], c->stream));
-    if (c->ua.npairs > 0) {
-        int nwg = (int)std::min<uint64_t>(c->ua.npairs, 4096);
-        int r = srk_unite(&c->ua, nwg, c->stream);
-        if (r) return fail(SR_ERR_HIP, std::string("unite kernel launch failed: ") + hipGetErrorString((hipError_t)r));
+    c->ev_used[1] = 0;
+    return enqueue_unite_batch(c, 0);
+}
+
+// alignment + match-run extraction + unite of the whole pair list, batch after batch (no host sync)
+extern "C" int sr_ctx_run(sr_ctx *c) {
+    if (!c || !c->loaded) return fail(SR_ERR_INVALID, "context not loaded");
+    int r = begin_pass(c, !c->from_paf);
+    if (r) return r;
+    c->ev_used[1] = 0;
+    const uint32_t nbatch = (uint32_t)c->batch_first.size() - 1;
+    for (uint32_t b = 0; b < nbatch; b++) {
+        if (!c->from_paf && (r = enqueue_align_batch(c, b))) return r;
+        if ((r = enqueue_unite_batch(c, b))) return r;
     }
-    HIPCHK(hipEventRecord(c->ev[1][1], c->stream));
-    c->ev_valid[1] = true;
+    c->aligned_batch_valid = nbatch == 1 && !c->from_paf;
     return SR_OK;
 }
 
@@ -571,9 +902,25 @@ extern "C" int sr_ctx_sync(sr_ctx *c) {
         int err = 0;
         HIPCHK(hipMemcpy(&err, c->d_error, sizeof(int), hipMemcpyDeviceToHost));
         if (err) {
-            char buf[128];
-            snprintf(buf, sizeof(buf), "device reported internal fault bits 0x%x", err);
-            return fail(SR_ERR_DEVICE_FAULT, buf);
+            static const char *names[8] = {"score bound exceeded", "base-case history overflow", "backtrace found no predecessor",
+                                           "recursion stack / segment list overflow", "CIGAR buffer overflow", "union-find retry bound",
+                                           "breakpoint outside its segment", "graph induction"};
+            std::string msg = "device reported internal fault bits";
+            char buf[32];
+            snprintf(buf, sizeof(buf), " 0x%x:", err);
+            msg += buf;
+            for (int b = 0; b < 8; b++) if (err & (1 << b)) { msg += " ["; msg += names[b]; msg += "]"; }
+            // which pair(s): a failed alignment leaves score -1
+            if (!c->from_paf && c->aa.score) {
+                const size_t np = c->pair_q.size();
+                std::vector<int32_t> sc(np);
+                if (np && hipMemcpy(sc.data(), c->aa.score, np * 4, hipMemcpyDeviceToHost) == hipSuccess) {
+                    int shown = 0;
+                    for (size_t i = 0; i < np && shown < 4; i++)
+                        if (sc[i] < 0) { snprintf(buf, sizeof(buf), " pair(%u,%u)", c->pair_q[i], c->pair_t[i]); msg += buf; shown++; }
+                }
+            }
+            return fail(SR_ERR_DEVICE_FAULT, msg);
         }
     }
     return SR_OK;
@@ -589,9 +936,15 @@ extern "C" const char *sr_ctx_align_kernel(const sr_ctx *c) {
 }
 
 extern "C" int sr_ctx_kernel_ms(sr_ctx *c, int which, float *ms) {
-    if (!c || which < 0 || which > 4 || !c->ev_valid[which]) return fail(SR_ERR_INVALID, "no timing recorded");
-    HIPCHK(hipEventSynchronize(c->ev[which][1]));
-    HIPCHK(hipEventElapsedTime(ms, c->ev[which][0], c->ev[which][1]));
+    if (!c || which < 0 || which > 4 || c->ev_used[which] == 0) return fail(SR_ERR_INVALID, "no timing recorded");
+    float tot = 0;
+    for (int i = 0; i < c->ev_used[which]; i++) {
+        float t = 0;
+        HIPCHK(hipEventSynchronize(c->ev[which][i].second));
+        HIPCHK(hipEventElapsedTime(&t, c->ev[which][i].first, c->ev[which][i].second));
+        tot += t;
+    }
+    *ms = tot;
     return SR_OK;
 }
 
@@ -603,6 +956,14 @@ extern "C" int sr_ctx_counters(sr_ctx *c, uint64_t out[16]) {
     return SR_OK;
 }
 
+extern "C" int sr_ctx_counters_ext(sr_ctx *c, uint64_t out[32]) {
+    if (!c || !c->loaded) return fail(SR_ERR_INVALID, "context not loaded");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, c->d_counters, SR_NCOUNTERS * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+
 extern "C" int sr_ctx_download_uf(sr_ctx *c, uint64_t *parent_out) {
     if (!c || !c->loaded) return fail(SR_ERR_INVALID, "context not loaded");
     HIPCHK(hipSetDevice(c->device));
@@ -611,21 +972,47 @@ extern "C" int sr_ctx_download_uf(sr_ctx *c, uint64_t *parent_out) {
     return SR_OK;
 }
 
+static int labels_timed(sr_ctx *c, uint64_t *dev_labels64, uint32_t *dev_labels32) {
+    hipEvent_t *e0, *e1;
+    int r;
+    if ((r = ev_get(c, 2, 0, &e0, &e1))) return r;
+    HIPCHK(hipEventRecord(*e0, c->stream));
+    if (dev_labels64) {
+        if (srk_labels(c->d_nodes, c->uf_size, c->d_minarr, (unsigned long long *)dev_labels64, c->d_error, c->stream))
+            return fail(SR_ERR_HIP, "label kernel launch failed");
+    } else {
+        if (srk_labels32(c->d_nodes, c->uf_size, c->d_minarr, dev_labels32, c->d_error, c->stream))
+            return fail(SR_ERR_HIP, "label kernel launch failed");
+    }
+    HIPCHK(hipEventRecord(*e1, c->stream));
+    c->ev_used[2] = 1;
+    return SR_OK;
+}
+
 extern "C" int sr_ctx_labels_device(sr_ctx *c, uint64_t *dev_labels) {
     if (!c || !c->loaded) return fail(SR_ERR_INVALID, "context not loaded");
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipEventRecord(c->ev[2][0], c->stream));
-    if (srk_labels(c->d_nodes, c->uf_size, c->d_minarr, (unsigned long long *)dev_labels, c->d_error, c->stream))
-        return fail(SR_ERR_HIP, "label kernel launch failed");
-    HIPCHK(hipEventRecord(c->ev[2][1], c->stream));
-    c->ev_valid[2] = true;
-    return SR_OK;
+    return labels_timed(c, dev_labels, nullptr);
+}
+extern "C" int sr_ctx_labels_device_u32(sr_ctx *c, uint32_t *dev_labels) {
+    if (!c || !c->loaded) return fail(SR_ERR_INVALID, "context not loaded");
+    if (c->uf_size > 0xffffffffULL) return fail(SR_ERR_UNSUPPORTED, "2N+2 >= 2^32: use the 64-bit label exchange");
+    HIPCHK(hipSetDevice(c->device));
+    return labels_timed(c, nullptr, dev_labels);
 }
 
 extern "C" int sr_ctx_merge_labels(sr_ctx *c, const uint64_t *dev_labels, uint32_t count) {
     if (!c || !c->loaded) return fail(SR_ERR_INVALID, "context not loaded");
     HIPCHK(hipSetDevice(c->device));
     if (srk_merge(c->d_nodes, c->uf_size, (const unsigned long long *)dev_labels, count, c->d_error, c->stream))
+        return fail(SR_ERR_HIP, "merge kernel launch failed");
+    return SR_OK;
+}
+extern "C" int sr_ctx_merge_labels_u32(sr_ctx *c, const uint32_t *dev_labels, uint32_t count) {
+    if (!c || !c->loaded) return fail(SR_ERR_INVALID, "context not loaded");
+    if (c->uf_size > 0xffffffffULL) return fail(SR_ERR_UNSUPPORTED, "2N+2 >= 2^32: use the 64-bit label exchange");
+    HIPCHK(hipSetDevice(c->device));
+    if (srk_merge32(c->d_nodes, c->uf_size, dev_labels, count, c->d_error, c->stream))
         return fail(SR_ERR_HIP, "merge kernel launch failed");
     return SR_OK;
 }
@@ -647,19 +1034,33 @@ extern "C" void sr_alignments_free(sr_alignments *a) {
     free(a);
 }
 
-extern "C" int sr_ctx_alignments(sr_ctx *c, sr_alignments **out) {
-    if (!c || !c->loaded) return fail(SR_ERR_INVALID, "context not loaded");
-    if (c->from_paf) return fail(SR_ERR_INVALID, "context was loaded from a PAF file: it holds no device alignments");
-    int r = sr_ctx_sync(c);
-    if (r) return r;
+// host copy of the alignments of batch b (its CIGARs must still be in the arena), appended to `ops`
+struct AlnAcc { std::vector<uint32_t> cnt, ops; std::vector<int32_t> score; std::vector<uint8_t> isrev; };
+static int collect_batch(sr_ctx *c, uint32_t b, AlnAcc &acc) {
+    const uint32_t f = c->batch_first[b], l = c->batch_first[b + 1], cntp = l - f;
+    if (cntp == 0) return SR_OK;
+    std::vector<uint32_t> cnt(cntp);
+    HIPCHK(hipMemcpy(cnt.data(), c->aa.cigar_cnt + f, (size_t)cntp * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(acc.score.data() + f, c->aa.score + f, (size_t)cntp * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(acc.isrev.data() + f, c->aa.is_reverse + f, (size_t)cntp, hipMemcpyDeviceToHost));
+    const uint64_t arena_used = c->cigar_base[l] - c->cigar_base[f];
+    std::vector<uint32_t> raw(arena_used + 1);
+    HIPCHK(hipMemcpy(raw.data(), c->aa.cigar_ops, (arena_used + 1) * 4, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < cntp; i++) {
+        acc.cnt[f + i] = cnt[i];
+        const uint32_t *src = raw.data() + (c->cigar_base[f + i] - c->cigar_base[f]);
+        for (uint32_t j = 0; j < cnt[i]; j++) {
+            const uint32_t op = src[j] & 15u, len = src[j] >> 4;
+            // raw WFA2 alphabet -> reference alphabet (src/wfa.rs:25-31): M->'=', I<->D swapped
+            const uint32_t o2 = op == SR_OP_M ? 0u : op == SR_OP_X ? 1u : op == SR_OP_I ? 3u : 2u;
+            acc.ops.push_back((len << 4) | o2);
+        }
+    }
+    return SR_OK;
+}
+
+static sr_alignments *make_alignments(const sr_ctx *c, const AlnAcc &acc) {
     const size_t np = c->pair_q.size();
-    std::vector<uint32_t> cnt(np + 1), ops(c->cigar_base[np] + 1);
-    std::vector<int32_t> score(np + 1);
-    std::vector<uint8_t> isrev(np + 1);
-    HIPCHK(hipMemcpy(cnt.data(), c->aa.cigar_cnt, (np + 1) * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(score.data(), c->aa.score, (np + 1) * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(isrev.data(), c->aa.is_reverse, np + 1, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(ops.data(), c->aa.cigar_ops, (c->cigar_base[np] + 1) * 4, hipMemcpyDeviceToHost));
     sr_alignments *a = (sr_alignments *)calloc(1, sizeof(sr_alignments));
     a->n = np;
     const size_t m = np ? np : 1;
@@ -668,26 +1069,46 @@ extern "C" int sr_ctx_alignments(sr_ctx *c, sr_alignments **out) {
     a->query_start = (uint64_t *)malloc(m * 8); a->query_end = (uint64_t *)malloc(m * 8);
     a->target_start = (uint64_t *)malloc(m * 8); a->target_end = (uint64_t *)malloc(m * 8);
     a->cigar_off = (uint64_t *)malloc((np + 1) * 8);
-    uint64_t tot = 0;
-    for (size_t i = 0; i < np; i++) tot += cnt[i];
-    a->cigar_ops = (uint32_t *)malloc((tot ? tot : 1) * 4);
+    a->cigar_ops = (uint32_t *)malloc((acc.ops.size() ? acc.ops.size() : 1) * 4);
+    memcpy(a->cigar_ops, acc.ops.data(), acc.ops.size() * 4);
     uint64_t w = 0;
     for (size_t i = 0; i < np; i++) {
         a->query_idx[i] = c->pair_q[i]; a->target_idx[i] = c->pair_t[i];
-        a->is_reverse[i] = isrev[i]; a->score[i] = score[i];
+        a->is_reverse[i] = acc.isrev[i]; a->score[i] = acc.score[i];
         a->query_start[i] = 0; a->query_end[i] = c->len[c->pair_q[i]];     // allwave aligns full sequences (seqrush.rs:743-753)
         a->target_start[i] = 0; a->target_end[i] = c->len[c->pair_t[i]];
         a->cigar_off[i] = w;
-        const uint32_t *src = ops.data() + c->cigar_base[i];
-        for (uint32_t j = 0; j < cnt[i]; j++) {
-            uint32_t op = src[j] & 15u, len = src[j] >> 4;
-            // raw WFA2 alphabet -> reference alphabet (src/wfa.rs:25-31): M->'=', I<->D swapped
-            uint32_t o2 = op == SR_OP_M ? 0u : op == SR_OP_X ? 1u : op == SR_OP_I ? 3u : 2u;
-            a->cigar_ops[w++] = (len << 4) | o2;
-        }
+        w += acc.cnt[i];
     }
     a->cigar_off[np] = w;
-    *out = a;
+    return a;
+}
+
+extern "C" int sr_ctx_alignments(sr_ctx *c, sr_alignments **out) {
+    if (!c || !c->loaded) return fail(SR_ERR_INVALID, "context not loaded");
+    if (c->from_paf) return fail(SR_ERR_INVALID, "context was loaded from a PAF file: it holds no device alignments");
+    if (c->batch_first.size() > 2 || !c->aligned_batch_valid)
+        return fail(SR_ERR_UNSUPPORTED, "the CIGARs of this context are not resident (several batches, or no alignment pass yet): use sr_align_all");
+    int r = sr_ctx_sync(c);
+    if (r) return r;
+    const size_t np = c->pair_q.size();
+    AlnAcc acc;
+    acc.cnt.assign(np + 1, 0); acc.score.assign(np + 1, 0); acc.isrev.assign(np + 1, 0);
+    if ((r = collect_batch(c, 0, acc))) return r;
+    *out = make_alignments(c, acc);
+    return SR_OK;
+}
+
+// per-pair results that stay resident for every batch: score, strand flag, CIGAR op count (arrays of num_pairs)
+extern "C" int sr_ctx_pair_results(sr_ctx *c, int32_t *score, uint8_t *is_reverse, uint32_t *cigar_ops) {
+    if (!c || !c->loaded || c->from_paf) return fail(SR_ERR_INVALID, "context holds no device alignments");
+    int r = sr_ctx_sync(c);
+    if (r) return r;
+    const size_t np = c->pair_q.size();
+    if (!np) return SR_OK;
+    if (score) HIPCHK(hipMemcpy(score, c->aa.score, np * 4, hipMemcpyDeviceToHost));
+    if (is_reverse) HIPCHK(hipMemcpy(is_reverse, c->aa.is_reverse, np, hipMemcpyDeviceToHost));
+    if (cigar_ops) HIPCHK(hipMemcpy(cigar_ops, c->aa.cigar_cnt, np * 4, hipMemcpyDeviceToHost));
     return SR_OK;
 }
 
@@ -705,12 +1126,38 @@ extern "C" size_t sr_alignment_cigar(const sr_alignments *a, uint64_t i, char *b
     return need;
 }
 
+// one batch at a time: align, copy its CIGARs to the host, (optionally) unite, next batch
+static int align_all_impl(sr_ctx *c, bool unite, sr_alignments **out) {
+    int r = begin_pass(c, true);
+    if (r) return r;
+    c->ev_used[1] = 0;
+    const size_t np = c->pair_q.size();
+    AlnAcc acc;
+    acc.cnt.assign(np + 1, 0); acc.score.assign(np + 1, 0); acc.isrev.assign(np + 1, 0);
+    const uint32_t nbatch = (uint32_t)c->batch_first.size() - 1;
+    for (uint32_t b = 0; b < nbatch; b++) {
+        if ((r = enqueue_align_batch(c, b))) return r;
+        if (unite && (r = enqueue_unite_batch(c, b))) return r;
+        if ((r = sr_ctx_sync(c))) return r;
+        if ((r = collect_batch(c, b, acc))) return r;
+    }
+    c->aligned_batch_valid = nbatch == 1;
+    *out = make_alignments(c, acc);
+    return SR_OK;
+}
+
+extern "C" int sr_ctx_align_all(sr_ctx *c, int unite, sr_alignments **out) {
+    if (!c || !c->loaded || !out) return fail(SR_ERR_INVALID, "context not loaded");
+    if (c->from_paf) return fail(SR_ERR_INVALID, "context was loaded from a PAF file: there is no alignment stage");
+    return align_all_impl(c, unite != 0, out);
+}
+
 extern "C" int sr_align_all(const sr_seqset *seqs, const sr_params *p, sr_alignments **out) {
     if (!seqs || !p || !out) return fail(SR_ERR_INVALID, "null argument");
     sr_ctx *c = nullptr;
     int r = sr_ctx_create(p->device, &c);
     if (r) return r;
-    if (!(r = sr_ctx_load(c, seqs, p)) && !(r = sr_ctx_align(c))) r = sr_ctx_alignments(c, out);
+    if (!(r = sr_ctx_load(c, seqs, p))) r = align_all_impl(c, false, out);
     std::string keep = g_err;
     sr_ctx_destroy(c);
     g_err = keep;
@@ -722,7 +1169,7 @@ extern "C" int sr_align_and_unite(const sr_seqset *seqs, const sr_params *p, uin
     sr_ctx *c = nullptr;
     int r = sr_ctx_create(p->device, &c);
     if (r) return r;
-    if (!(r = sr_ctx_load(c, seqs, p)) && !(r = sr_ctx_align(c)) && !(r = sr_ctx_unite(c)) && !(r = sr_ctx_sync(c))) {
+    if (!(r = sr_ctx_load(c, seqs, p)) && !(r = sr_ctx_run(c)) && !(r = sr_ctx_sync(c))) {
         if (p->canonical_labels) r = sr_ctx_download_labels(c, parent_out);
         else r = sr_ctx_download_uf(c, parent_out);
         if (!r) r = sr_ctx_sync(c);
@@ -732,7 +1179,6 @@ extern "C" int sr_align_and_unite(const sr_seqset *seqs, const sr_params *p, uin
     g_err = keep;
     return r;
 }
-
 
 // ------------------------------------------------------------------ PAF input (seam 3, `seqrush -p`)
 // SeqRush::align_and_unite_from_paf (src/seqrush.rs:510-609) + process_alignment (:1134-1481): every PAF
@@ -879,12 +1325,12 @@ extern "C" int sr_ctx_load_paf(sr_ctx *c, const sr_seqset *seqs, const sr_params
     DEV_UP(c->d_max_score, int32_t, std::vector<int32_t>(np ? np : 1, INT_MAX));   // no divergence filter on PAF input
 #undef DEV_UP
     if ((r = dev_alloc(c, &d, sizeof(uint32_t)))) return r; c->d_queue = (uint32_t *)d;
-    if ((r = dev_alloc(c, &d, 16 * sizeof(unsigned long long)))) return r; c->d_counters = (unsigned long long *)d;
+    if ((r = dev_alloc(c, &d, SR_NCOUNTERS * sizeof(unsigned long long)))) return r; c->d_counters = (unsigned long long *)d;
     if ((r = dev_alloc(c, &d, sizeof(int)))) return r; c->d_error = (int *)d;
     if ((r = dev_alloc(c, &d, c->uf_size * 8))) return r; c->d_nodes = (unsigned long long *)d;
     if ((r = dev_alloc(c, &d, c->uf_size * 8))) return r; c->d_minarr = (unsigned long long *)d;
     if ((r = dev_alloc(c, &d, c->uf_size * 8))) return r; c->d_labels = (unsigned long long *)d;
-    HIPCHK(hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream));
+    HIPCHK(hipMemsetAsync(c->d_counters, 0, SR_NCOUNTERS * sizeof(unsigned long long), c->stream));
     HIPCHK(hipMemsetAsync(c->d_error, 0, sizeof(int), c->stream));
     a.npairs = 0; a.counters = c->d_counters; a.error_flag = c->d_error;
     SrUniteArgs &u = c->ua;
@@ -895,6 +1341,8 @@ extern "C" int sr_ctx_load_paf(sr_ctx *c, const sr_seqset *seqs, const sr_params
     u.cigar_ops = d_ops; u.cigar_base = d_cbase; u.cigar_cnt = d_cnt;
     u.min_match_len = p->min_match_len; u.nodes = c->d_nodes; u.uf_size = c->uf_size;
     u.counters = c->d_counters; u.error_flag = c->d_error;
+    c->batch_first.assign(1, 0); c->batch_first.push_back(np);          // PAF records: one batch
+    c->d_cbase = d_cbase; c->total_pairs_all_ranks = recno;
     if (srk_uf_init(c->d_nodes, c->total_len, c->uf_size, c->stream)) return fail(SR_ERR_HIP, "uf init launch failed");
     HIPCHK(hipStreamSynchronize(c->stream));
     c->loaded = true; c->from_paf = true;
@@ -906,7 +1354,7 @@ extern "C" int sr_unite_paf(const sr_seqset *seqs, const sr_params *p, const cha
     sr_ctx *c = nullptr;
     int r = sr_ctx_create(p->device, &c);
     if (r) return r;
-    if (!(r = sr_ctx_load_paf(c, seqs, p, paf_path)) && !(r = sr_ctx_unite(c)) && !(r = sr_ctx_sync(c))) {
+    if (!(r = sr_ctx_load_paf(c, seqs, p, paf_path)) && !(r = sr_ctx_run(c)) && !(r = sr_ctx_sync(c))) {
         if (p->canonical_labels) r = sr_ctx_download_labels(c, parent_out);
         else r = sr_ctx_download_uf(c, parent_out);
         if (!r) r = sr_ctx_sync(c);
@@ -1080,13 +1528,15 @@ extern "C" int sr_ctx_build_gfa(sr_ctx *c, const sr_seqset *seqs, char **gfa, ui
         !d_hkeys || !d_edges) return fail(SR_ERR_NOMEM, "not enough device memory for graph induction");
     HIPCHK(hipMemcpyAsync(d_bases, seqs->bases, N, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(d_islast, islast.data(), N, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipEventRecord(c->ev[3][0], c->stream));
+    hipEvent_t *ge0, *ge1;
+    if ((r = ev_get(c, 3, 0, &ge0, &ge1))) return r;
+    HIPCHK(hipEventRecord(*ge0, c->stream));
     // d_minarr (uf_size entries) is free again once the labels exist: first-position table
     if (srk_graph_induce(c->d_labels, d_bases, d_islast, N, c->uf_size, c->d_minarr, d_flag, d_nid, d_steps, d_nbase, d_hkeys,
                          d_hvals, hcap, d_eslot, d_edges, d_tiles, d_counts, c->d_error, c->stream))
         return fail(SR_ERR_HIP, "graph induction launch failed");
-    HIPCHK(hipEventRecord(c->ev[3][1], c->stream));
-    c->ev_valid[3] = true;
+    HIPCHK(hipEventRecord(*ge1, c->stream));
+    c->ev_used[3] = 1;
     if ((r = sr_ctx_sync(c))) return r;
     uint32_t counts[2] = {0, 0};
     HIPCHK(hipMemcpy(counts, d_counts, 8, hipMemcpyDeviceToHost));

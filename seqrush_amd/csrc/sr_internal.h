@@ -42,6 +42,10 @@ struct SrAlignArgs {
     const uint32_t *seqwords;
     const uint64_t *word_off_fwd;   // [n] index of the first real word
     const uint64_t *word_off_rc;    // [n] same for the reverse complement
+    const uint64_t *word_off_rev;   // [n] reversed copy (2-bit ACGT buffers: == word_off_rc, see sr_align_blk.inc)
+    const uint64_t *word_off_cmp;   // [n] complemented copy (2-bit ACGT buffers: == word_off_fwd)
+    int symbits;                    // 2, 4 or 8 bits per symbol (selects the kernel build, sr_dev_common.h)
+    const uint32_t *order;          // [npairs] dequeue order (cost-sorted), NULL = list order
     const uint32_t *seqlen;         // [n]
     uint32_t max_words;             // words per LDS region (incl. pads)
     // pair list (this rank's shard)
@@ -84,6 +88,7 @@ struct SrAlignArgs {
     int pre_oriented;          // 1: is_reverse / ori_fwd / ori_rev are inputs of the alignment kernel
     int lazy_id;               // impl 2: searches in phase 1 do not store the I/D rows only breakpoint detection reads
                                //   (kdepth >= 2 * scope + 2 * block + 2 so that they can be recomputed)
+    int profile_ticks;         // impl 2: launch the instrumented instance (SR_PROFILE_TICKS=1)
     int *bmak;                 // impl 2: per workgroup [32 aligners][32 ring levels] max M antidiagonal (breakpoint pruning)
     // outputs
     uint8_t *is_reverse;       // [npairs]
@@ -92,9 +97,10 @@ struct SrAlignArgs {
     uint32_t *cigar_ops;
     const uint64_t *cigar_base;// [npairs+1]
     uint32_t *cigar_cnt;       // [npairs]
-    unsigned long long *counters; // [8]
+    unsigned long long *counters; // [SR_NCOUNTERS]
     int *error_flag;
 };
+#define SR_NCOUNTERS 32
 
 struct SrUniteArgs {
     const uint32_t *pair_q, *pair_t;
@@ -119,7 +125,7 @@ struct SrUniteArgs {
 extern "C" {
 #endif
 // launchers implemented in sr_device.hip (hipStream_t passed as void*)
-int srk_align(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, int nthreads, void *stream);
+int srk_align(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, int nthreads, void *stream);   // by a->impl, a->symbits
 int srk_unite(const SrUniteArgs *a, int nwg, void *stream);
 int srk_uf_init(unsigned long long *nodes, uint64_t total_len, uint64_t uf_size, void *stream);
 int srk_labels(unsigned long long *nodes, uint64_t uf_size, unsigned long long *minarr,
@@ -134,6 +140,16 @@ int srk_graph_induce(const unsigned long long *labels, const uint8_t *bases, con
                      uint64_t hcap, uint32_t *eslot, unsigned long long *edges, uint32_t *tile_sum,
                      uint32_t *counts, int *error_flag, void *stream);
 int srk_align_blk_supports(const SrPen *pen, const SrPen *ori);   // levels per block, 0 = no blocked instance
+int srk_labels32(unsigned long long *nodes, uint64_t uf_size, unsigned long long *minarr, uint32_t *labels, int *error_flag,
+                 void *stream);
+int srk_merge32(unsigned long long *nodes, uint64_t uf_size, const uint32_t *labels, uint32_t count, int *error_flag, void *stream);
+// sr_sketch.hip: k-mer bottom-s sketches, all-pairs similarity, k-nearest / k-farthest selection
+int srk_sketch(const uint8_t *bases, const uint64_t *goff, const uint32_t *len, uint32_t n, int k, int s_max,
+               unsigned long long *scratch, uint64_t stride, const uint32_t *npad, unsigned long long *sketch, uint32_t *sk_n,
+               void *stream);
+int srk_jaccard(const unsigned long long *sketch, const uint32_t *sk_n, uint32_t n, int s_max, uint32_t *shared, uint32_t *denom,
+                void *stream);
+int srk_knn_select(const uint32_t *shared, const uint32_t *denom, uint32_t n, int kn, int kf, uint8_t *sel, void *stream);
 #ifdef __cplusplus
 }
 #endif

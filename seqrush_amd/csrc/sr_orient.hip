@@ -11,6 +11,7 @@
 // ranges are scalar arithmetic, and 16 pairs per CU keep the SIMDs busy.  Tile code = sr_align_blk.inc's
 // blk_tile for one level (4 diagonals per lane, DPP neighbours, 2 halo lanes).
 #include "sr_dev_common.h"
+namespace SR_NS {
 
 __device__ __forceinline__ int o_lane_left(int x) { return __builtin_amdgcn_update_dpp(NULLV, x, 0x138, 0xf, 0xf, false); }
 __device__ __forceinline__ int o_lane_right(int x) { return __builtin_amdgcn_update_dpp(NULLV, x, 0x130, 0xf, 0xf, false); }
@@ -32,9 +33,10 @@ __global__ void __launch_bounds__(64, 4) sr_orient_kernel(SrAlignArgs a) {
         if (lane == 0) pair = (int)atomicAdd(a.oqueue, 1u);
         pair = RFL(pair);
         if (pair >= (int)a.npairs) break;
+        if (a.order) pair = (int)a.order[pair];                 // cost-sorted dequeue order
         const uint32_t q = a.pair_q[pair], t = a.pair_t[pair];
         const int plen = (int)a.seqlen[q], tlen = (int)a.seqlen[t];
-        const int pw = ((plen + 15) >> 4) + 2, tw = ((tlen + 15) >> 4) + 2;
+        const int pw = SR_SEQ_WORDS(plen), tw = SR_SEQ_WORDS(tlen);
         __syncthreads();                                        // (one wave: orders the LDS reuse)
         load_seq_lds<64>(lds_seq, (GP<const uint32_t>)a.seqwords + a.word_off_fwd[q] - 1, pw);
         load_seq_lds<64>(lds_seq + a.max_words, (GP<const uint32_t>)a.seqwords + a.word_off_rc[q] - 1, pw);
@@ -97,10 +99,10 @@ __global__ void __launch_bounds__(64, 4) sr_orient_kernel(SrAlignArgs a) {
                         const int h = valid ? mv[qq] : 0, v = valid ? mv[qq] - (k0 + qq) : 0;
                         const int nn = valid ? min(plen - v, tlen - h) : 0;
                         const uint32_t xw = win_fwd(P, v) ^ win_fwd(T, h);
-                        const unsigned z = (unsigned)(__ffs((int)xw) - 1) >> 1;
-                        const int c = (int)min(min(z, 16u), (unsigned)nn);
+                        const unsigned z = (unsigned)(__ffs((int)xw) - 1) >> SR_SYM_LOG;
+                        const int c = (int)min(min(z, (unsigned)SR_WIN), (unsigned)nn);
                         mv[qq] += c;
-                        more |= (xw == 0u && nn > 16) ? (1 << qq) : 0;
+                        more |= (xw == 0u && nn > SR_WIN) ? (1 << qq) : 0;
                     }
                     unsigned long long pend[4];
 #pragma unroll
@@ -113,10 +115,10 @@ __global__ void __launch_bounds__(64, 4) sr_orient_kernel(SrAlignArgs a) {
                             const int h = on ? mv[qq] : 0, v = on ? mv[qq] - (k0 + qq) : 0;
                             const int nn = on ? min(plen - v, tlen - h) : 0;
                             const uint32_t xw = win_fwd(P, v) ^ win_fwd(T, h);
-                            const unsigned z = (unsigned)(__ffs((int)xw) - 1) >> 1;
-                            const int c = (int)min(min(z, 16u), (unsigned)nn);
+                            const unsigned z = (unsigned)(__ffs((int)xw) - 1) >> SR_SYM_LOG;
+                            const int c = (int)min(min(z, (unsigned)SR_WIN), (unsigned)nn);
                             mv[qq] += c;
-                            if (!(xw == 0u && nn > 16)) more &= ~(1 << qq);
+                            if (!(xw == 0u && nn > SR_WIN)) more &= ~(1 << qq);
                             pend[qq] = __ballot((more >> qq) & 1);
                         }
                     }
@@ -150,7 +152,9 @@ __global__ void __launch_bounds__(64, 4) sr_orient_kernel(SrAlignArgs a) {
     }
 }
 
-extern "C" int srk_orient(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, void *stream) {
+}  // namespace
+using namespace SR_NS;
+extern "C" int SRK_NAME(srk_orient)(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     if (off16) {
         if (lds_bytes > 32 * 1024) {

@@ -183,6 +183,29 @@ __global__ void sr_label_kernel(unsigned long long *nodes, unsigned long long n,
     }
     if (err) atomicOr(error_flag, err);
 }
+// 32-bit label exchange (u32 when 2N+2 < 2^32 -- half the xGMI bytes of the all-gather)
+__global__ void sr_label32_kernel(unsigned long long *nodes, unsigned long long n, const unsigned long long *minarr,
+                                  uint32_t *labels, int *error_flag) {
+    int err = 0;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const unsigned long long r = uf_find(nodes, i, err);
+        labels[i] = (uint32_t)minarr[r];
+    }
+    if (err) atomicOr(error_flag, err);
+}
+__global__ void sr_merge32_kernel(unsigned long long *nodes, unsigned long long n, const uint32_t *labels, unsigned count,
+                                  int *error_flag) {
+    int err = 0;
+    const unsigned long long total = n * (unsigned long long)count;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long j = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += stride) {
+        const unsigned long long i = j % n;
+        const unsigned long long l = labels[j];
+        if (l != i && l < n) uf_unite(nodes, i, l, err);
+    }
+    if (err) atomicOr(error_flag, err);
+}
 // replay-unite of `count` gathered label arrays
 __global__ void sr_merge_kernel(unsigned long long *nodes, unsigned long long n,
                                 const unsigned long long *labels, unsigned count, int *error_flag) {
@@ -197,14 +220,36 @@ __global__ void sr_merge_kernel(unsigned long long *nodes, unsigned long long n,
     if (err) atomicOr(error_flag, err);
 }
 
+// every kernel family is built once per symbol width of the packed sequence buffer (sr_dev_common.h SR_SYMBITS)
+#define SRK_DECL_ALIGN(name)                                                                                              \
+    extern "C" int name##_s2(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, int nthreads, void *stream);     \
+    extern "C" int name##_s4(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, int nthreads, void *stream);     \
+    extern "C" int name##_s8(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, int nthreads, void *stream);
+SRK_DECL_ALIGN(srk_align_bfs)
+SRK_DECL_ALIGN(srk_align_blk)
 extern "C" int srk_align_v3(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, int nthreads, void *stream);
-extern "C" int srk_align_bfs(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, int nthreads, void *stream);
-extern "C" int srk_align_blk(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, int nthreads, void *stream);
+extern "C" int srk_orient_s2(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, void *stream);
+extern "C" int srk_orient_s4(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, void *stream);
+extern "C" int srk_orient_s8(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, void *stream);
 
 extern "C" int srk_align(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, int nthreads, void *stream) {
-    if (a->impl == 2) return srk_align_blk(a, nwg, lds_bytes, off16, nthreads, stream);
-    if (a->impl == 1) return srk_align_bfs(a, nwg, lds_bytes, off16, nthreads, stream);
+    if (a->impl == 2) {
+        if (a->symbits == 8) return srk_align_blk_s8(a, nwg, lds_bytes, off16, nthreads, stream);
+        if (a->symbits == 4) return srk_align_blk_s4(a, nwg, lds_bytes, off16, nthreads, stream);
+        return srk_align_blk_s2(a, nwg, lds_bytes, off16, nthreads, stream);
+    }
+    if (a->impl == 1) {
+        if (a->symbits == 8) return srk_align_bfs_s8(a, nwg, lds_bytes, off16, nthreads, stream);
+        if (a->symbits == 4) return srk_align_bfs_s4(a, nwg, lds_bytes, off16, nthreads, stream);
+        return srk_align_bfs_s2(a, nwg, lds_bytes, off16, nthreads, stream);
+    }
+    if (a->symbits != 2) return (int)hipErrorInvalidValue;     // sr_align_kernel is built for 2-bit buffers only (host checks)
     return srk_align_v3(a, nwg, lds_bytes, off16, nthreads, stream);
+}
+extern "C" int srk_orient(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, void *stream) {
+    if (a->symbits == 8) return srk_orient_s8(a, nwg, lds_bytes, off16, stream);
+    if (a->symbits == 4) return srk_orient_s4(a, nwg, lds_bytes, off16, stream);
+    return srk_orient_s2(a, nwg, lds_bytes, off16, stream);
 }
 
 extern "C" int srk_unite(const SrUniteArgs *a, int nwg, void *stream) {
@@ -238,5 +283,25 @@ extern "C" int srk_merge(unsigned long long *nodes, uint64_t uf_size, const unsi
     const int nb = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
     hipLaunchKernelGGL(sr_merge_kernel, dim3(nb ? nb : 1), dim3(256), 0, (hipStream_t)stream, nodes,
                        (unsigned long long)uf_size, labels, count, error_flag);
+    return (int)hipGetLastError();
+}
+
+extern "C" int srk_labels32(unsigned long long *nodes, uint64_t uf_size, unsigned long long *minarr, uint32_t *labels,
+                            int *error_flag, void *stream) {
+    const int nb = (int)((uf_size + 255) / 256 > 4096 ? 4096 : (uf_size + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(sr_fill_kernel, dim3(nb ? nb : 1), dim3(256), 0, st, minarr, (unsigned long long)uf_size, ~0ULL);
+    hipLaunchKernelGGL(sr_minroot_kernel, dim3(nb ? nb : 1), dim3(256), 0, st, nodes, (unsigned long long)uf_size, minarr, error_flag);
+    hipLaunchKernelGGL(sr_label32_kernel, dim3(nb ? nb : 1), dim3(256), 0, st, nodes, (unsigned long long)uf_size, minarr, labels,
+                       error_flag);
+    return (int)hipGetLastError();
+}
+
+extern "C" int srk_merge32(unsigned long long *nodes, uint64_t uf_size, const uint32_t *labels, uint32_t count, int *error_flag,
+                           void *stream) {
+    const uint64_t total = uf_size * count;
+    const int nb = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL(sr_merge32_kernel, dim3(nb ? nb : 1), dim3(256), 0, (hipStream_t)stream, nodes, (unsigned long long)uf_size,
+                       labels, count, error_flag);
     return (int)hipGetLastError();
 }

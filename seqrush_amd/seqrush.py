@@ -241,6 +241,50 @@ class Context:
         self.seqset = seqset
         check(self.L.sr_ctx_load(self._h, C.byref(seqset.c), C.byref(params.c)))
 
+    def load_pairs(self, seqset: SeqSet, params: Params, pairs):
+        """explicit ordered (query, target) pair list instead of the all-vs-all enumeration"""
+        self.seqset = seqset
+        q = np.ascontiguousarray([a for a, _ in pairs], dtype=np.uint32)
+        t = np.ascontiguousarray([b for _, b in pairs], dtype=np.uint32)
+        check(self.L.sr_ctx_load_pairs(self._h, C.byref(seqset.c), C.byref(params.c),
+                                       q.ctypes.data_as(C.POINTER(C.c_uint32)), t.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                       len(pairs)))
+
+    def pairs(self):
+        """this rank's (query, target) pair list after sparsification and sharding"""
+        q = C.POINTER(C.c_uint32)(); t = C.POINTER(C.c_uint32)(); cnt = C.c_uint64()
+        check(self.L.sr_ctx_pairs(self._h, C.byref(q), C.byref(t), C.byref(cnt)))
+        m = int(cnt.value)
+        qa = np.ctypeslib.as_array(q, shape=(max(m, 1),))[:m].copy()
+        ta = np.ctypeslib.as_array(t, shape=(max(m, 1),))[:m].copy()
+        self.L.sr_free(C.cast(q, C.c_void_p)); self.L.sr_free(C.cast(t, C.c_void_p))
+        return list(zip(qa.tolist(), ta.tolist()))
+
+    @property
+    def num_batches(self):
+        return int(self.L.sr_ctx_num_batches(self._h))
+
+    def workspace_report(self):
+        import json
+        return json.loads(self.L.sr_ctx_workspace_report(self._h).decode() or "{}")
+
+    def run(self):
+        """align + unite of the whole shard, batch after batch (PAF context: unite only)"""
+        check(self.L.sr_ctx_run(self._h))
+
+    def align_all(self, unite: bool = False) -> "Alignments":
+        p = C.POINTER(AlignmentsC)()
+        check(self.L.sr_ctx_align_all(self._h, 1 if unite else 0, C.byref(p)))
+        return Alignments(p)
+
+    def pair_results(self):
+        """(score, is_reverse, n_cigar_ops) arrays over this rank's pairs; resident for every batch"""
+        n = self.num_pairs
+        sc = np.zeros(max(n, 1), dtype=np.int32); rv = np.zeros(max(n, 1), dtype=np.uint8); co = np.zeros(max(n, 1), dtype=np.uint32)
+        check(self.L.sr_ctx_pair_results(self._h, sc.ctypes.data_as(C.POINTER(C.c_int32)),
+                                         rv.ctypes.data_as(C.POINTER(C.c_uint8)), co.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return sc[:n], rv[:n], co[:n]
+
     def load_paf(self, seqset: SeqSet, params: Params, paf_path: str):
         """`seqrush -p`: replay the records of a PAF file (then unite()); there is no alignment stage"""
         self.seqset = seqset
@@ -300,6 +344,12 @@ class Context:
     def merge_labels(self, dev_ptr: int, count: int):
         check(self.L.sr_ctx_merge_labels(self._h, C.c_void_p(dev_ptr), count))
 
+    def labels_device_u32(self, dev_ptr: int):
+        check(self.L.sr_ctx_labels_device_u32(self._h, C.c_void_p(dev_ptr)))
+
+    def merge_labels_u32(self, dev_ptr: int, count: int):
+        check(self.L.sr_ctx_merge_labels_u32(self._h, C.c_void_p(dev_ptr), count))
+
     @property
     def align_kernel(self) -> str:
         n = self.L.sr_ctx_align_kernel(self._h)
@@ -311,9 +361,10 @@ class Context:
         return float(ms.value)
 
     def counters(self):
-        out = (C.c_uint64 * 16)()
-        check(self.L.sr_ctx_counters(self._h, out))
-        return dict(wf_cells=int(out[0]), wf_steps=int(out[1]), base_segments=int(out[2]),
+        out = (C.c_uint64 * 32)()
+        check(self.L.sr_ctx_counters_ext(self._h, out))
+        return dict(row_bytes_loaded=int(out[16]), row_bytes_stored=int(out[17]),
+                    wf_cells=int(out[0]), wf_steps=int(out[1]), base_segments=int(out[2]),
                     breakpoint_searches=int(out[3]), united_bases=int(out[4]), match_runs=int(out[5]),
                     ticks_orientation=int(out[6]), ticks_breakpoint=int(out[7]), ticks_base=int(out[8]),
                     bp_passes=int(out[9]), ticks_pair=int(out[10]), tk_pass=int(out[11]),
@@ -375,7 +426,7 @@ class SeqRush:
         if args.paf is not None:                      # align_and_unite_from_paf (src/seqrush.rs:510-609)
             print(f"Reading alignments from PAF file: {args.paf}")
             self.ctx.load_paf(self.seqset, Params.from_args(args), args.paf)
-            self.ctx.unite()
+            self.ctx.run()
             self.ctx.sync()
             self.labels = self.ctx.download_labels()
             self.ctx.sync()
@@ -386,14 +437,14 @@ class SeqRush:
         self.ctx.load(self.seqset, params)
         n = len(self.sequences)
         print(f"Total sequence pairs: {n * n} (sparsification: {args.sparsification})")
-        self.ctx.align()
-        self.ctx.unite()
-        self.ctx.sync()
         if args.output_alignments:
-            al = self.ctx.alignments()
+            al = self.ctx.align_all(unite=True)         # batches: align, copy the CIGARs out, unite
             print(f"Writing alignments to {args.output_alignments}")
             al.write_paf(self.seqset, args.output_alignments)
             al.close()
+        else:
+            self.ctx.run()
+        self.ctx.sync()
         self.labels = self.ctx.download_labels()
         self.ctx.sync()
 

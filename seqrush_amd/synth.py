@@ -136,3 +136,90 @@ def config_c5_like(n: int = 4, L: int = 6000, seed: int = 5001):
             s = reverse_complement(s)
         out.append((name, s))
     return out
+
+
+# --------------------------------------------------------------------------- full-size configurations
+def indel_family_fast(n: int, L: int, sub: float, indel: float, seed: int, max_indel: int = 8, base=None):
+    """vectorised relative of indel_family for large inputs: per base position one event drawn from the counter
+    stream -- substitution (prob. sub), deletion of 1..max_indel bases starting there (indel/2), insertion of
+    1..max_indel random bases in front of it (indel/2); events that fall inside a deleted stretch are dropped"""
+    if base is None:
+        base = base_sequence(L, seed)
+    L = len(base)
+    out = []
+    idx = np.arange(L)
+    for i in range(n):
+        sd = seed + 1 + i
+        u = _unit(_r(sd, 4 * idx))
+        d = (_r(sd, 4 * idx + 1) % np.uint64(3)).astype(np.uint8) + 1
+        ln = (_r(sd, 4 * idx + 2) % np.uint64(max_indel)).astype(np.int64) + 1
+        is_sub = u < sub
+        is_del = (u >= sub) & (u < sub + indel / 2)
+        is_ins = (u >= sub + indel / 2) & (u < sub + indel)
+        diff = np.zeros(L + max_indel + 1, dtype=np.int64)
+        ds = np.nonzero(is_del)[0]
+        np.add.at(diff, ds, 1)
+        np.add.at(diff, ds + ln[ds], -1)
+        deleted = np.cumsum(diff)[:L] > 0
+        codes = np.where(is_sub, (base + d) & 3, base).astype(np.uint8)
+        keep = ~deleted
+        ins_pos = np.nonzero(is_ins & keep)[0]
+        if len(ins_pos):
+            reps = ln[ins_pos]
+            tot = int(reps.sum())
+            ins_codes = (_r(sd + 7919, np.arange(tot)) & np.uint64(3)).astype(np.uint8)
+            # position of every kept base in the output = its rank among kept bases + inserted bases before it
+            cum_ins = np.zeros(L, dtype=np.int64)
+            cum_ins[ins_pos] = reps
+            cum_ins = np.cumsum(cum_ins)                      # inclusive: insertion sits in front of its base
+            kept_idx = np.nonzero(keep)[0]
+            out_len = len(kept_idx) + tot
+            res = np.empty(out_len, dtype=np.uint8)
+            dst = np.arange(len(kept_idx)) + cum_ins[kept_idx]
+            res[dst] = codes[kept_idx]
+            mask = np.ones(out_len, dtype=bool)
+            mask[dst] = False
+            res[mask] = ins_codes
+        else:
+            res = codes[keep]
+        if len(res) == 0:
+            res = np.zeros(1, dtype=np.uint8)
+        out.append((f"seq{i}", to_bytes(res)))
+    return out
+
+
+def config_c3_surrogate(n: int = 12, L: int = 13500, seed: int = 3001):
+    """BASELINE.json configs[2] surrogate at the size SURVEY 8(d) states (HLA-zoo DRB1 itself is not in the
+    container): 12 sequences of ~13.5 kb, 3 % substitutions, 0.3 % short indels, two 200-800 bp insertions each"""
+    return config_c3_like(n, L, seed)
+
+
+def config_c4(n: int = 1024, L: int = 2000, clades: int = 16, seed: int = 4001):
+    """BASELINE.json configs[3]: 1024 x 2 kb, 16 clades x 64, 8 % between-clade and 1 % within-clade substitutions"""
+    root = base_sequence(L, seed)
+    per = max(1, n // clades)
+    out = []
+    for i in range(n):
+        c = min(i // per, clades - 1)
+        cb = substitute(root, 0.08, seed + 100 + c)
+        out.append((f"seq{i}", to_bytes(substitute(cb, 0.01, seed + 1000 + i))))
+    return out
+
+
+def config_c5(n: int = 256, L: int = 50000, seed: int = 5001):
+    """BASELINE.json configs[4]: 256 x 50 kb, 2 % substitutions, 0.1 % indels; 25 % of the sequences carry 1-3
+    segments of U[1000, 5000] bp reverse-complemented in place, 10 % are reverse-complemented entirely"""
+    fam = indel_family_fast(n, L, 0.02, 0.001, seed, max_indel=4)
+    out = []
+    for i, (name, s) in enumerate(fam):
+        r = _r(seed + 50000 + i, np.arange(16))
+        if int(r[0] % np.uint64(4)) == 0:                       # 25 %: in-place inversions
+            k = 1 + int(r[1] % np.uint64(3))
+            for j in range(k):
+                ln = 1000 + int(r[2 + 2 * j] % np.uint64(4001))
+                st = int(r[3 + 2 * j] % np.uint64(max(1, len(s) - ln)))
+                s = invert_segment(s, st, ln)
+        if int(r[10] % np.uint64(10)) == 0:                     # 10 %: whole sequence reverse-complemented
+            s = reverse_complement(s)
+        out.append((name, s))
+    return out

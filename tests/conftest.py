@@ -2,6 +2,9 @@ import os
 import sys
 
 import pytest
+# torch first: its wheel bundles a HIP runtime of its own; when libseqrush_amd.so (linked against /opt/rocm) is the first
+# to initialise HIP in the process, a later torch.cuda init finds "No HIP GPUs".  Loaded in this order both share torch's.
+import torch  # noqa: F401
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):

@@ -126,6 +126,12 @@ def lib():
     L.sro_align_and_unite.restype = C.c_int64
     L.sro_align_and_unite.argtypes = [C.POINTER(SeqRushS), C.POINTER(Params), u64, u64,
                                       C.POINTER(u64)]
+    L.sro_align_and_unite_list.restype = C.c_int64
+    L.sro_align_and_unite_list.argtypes = [C.POINTER(SeqRushS), C.POINTER(Params), C.POINTER(C.c_uint32),
+                                           C.POINTER(C.c_uint32), u64, C.POINTER(u64)]
+    L.sro_sparsified_pairs.argtypes = [C.POINTER(SeqRushS), C.POINTER(Sparsification), u64, i32,
+                                       C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(C.c_uint32)),
+                                       C.POINTER(u64)]
     L.sro_build_gfa.restype = vp
     L.sro_build_gfa.argtypes = [C.POINTER(SeqRushS), i32, i32, C.POINTER(u64), C.POINTER(u64)]
     L.sro_canonical_labels.argtypes = [C.POINTER(SeqRushS), C.POINTER(u64)]
@@ -243,6 +249,31 @@ class OracleSeqRush:
         if r < 0:
             raise RuntimeError("sro_align_and_unite failed")
         return r, cells.value
+
+    def align_and_unite_list(self, params: Params, pairs):
+        """the same over an explicit ordered (query, target) list"""
+        import numpy as np
+        q = np.ascontiguousarray([a for a, _ in pairs], dtype=np.uint32)
+        t = np.ascontiguousarray([b for _, b in pairs], dtype=np.uint32)
+        cells = C.c_uint64()
+        r = self.L.sro_align_and_unite_list(self.ptr, C.byref(params), q.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                            t.ctypes.data_as(C.POINTER(C.c_uint32)), len(pairs), C.byref(cells))
+        if r < 0:
+            raise RuntimeError("sro_align_and_unite_list failed")
+        return r, cells.value
+
+    def sparsified_pairs(self, spec: str, seed=42, exclude_self=False):
+        """ordered pair list of `-x spec` (own definition, unpinned: allwave's rules are not in the reference tree)"""
+        sp = Sparsification()
+        if self.L.sro_parse_sparsification(spec.encode(), C.byref(sp)) != 0:
+            raise ValueError(spec)
+        q = C.POINTER(C.c_uint32)(); t = C.POINTER(C.c_uint32)(); cnt = C.c_uint64()
+        if self.L.sro_sparsified_pairs(self.ptr, C.byref(sp), seed, int(exclude_self), C.byref(q), C.byref(t),
+                                       C.byref(cnt)) != 0:
+            raise RuntimeError("sro_sparsified_pairs failed")
+        out = [(int(q[i]), int(t[i])) for i in range(cnt.value)]
+        self.L._libc.free(C.cast(q, C.c_void_p)); self.L._libc.free(C.cast(t, C.c_void_p))
+        return out
 
     def find(self, pos):
         return self.L.sro_buf_find(self.uf, pos)

@@ -339,11 +339,11 @@ def test_error_paths(gpu):
         run_gpu([("a", b"ACGT"), ("b", b"")])
     assert e.value.code == -5 and "Empty sequences are not allowed" in str(e.value)
     with pytest.raises(sa.SeqRushError) as e:
-        run_gpu([("a", b"ACGTN"), ("b", b"ACGT")])
-    assert e.value.code == -4
+        run_gpu([("a", b"ACGT"), ("b", b"ACGT")], scores="2,4,4,2")       # the trait impl's own defaults (allwave_impl.rs:15-23)
+    assert e.value.code == -6 and "allwave_impl.rs" in str(e.value)
     with pytest.raises(sa.SeqRushError) as e:
-        run_gpu([("a", b"ACGT"), ("b", b"ACGT")], scores="2,4,4,2")
-    assert e.value.code == -6
+        run_gpu([("a", b"ACGT"), ("b", b"ACGT")], memory_mode=0)          # SR_MEM_HIGH: refused, not a silent biWFA
+    assert e.value.code == -6 and "Ultralow" in str(e.value).replace("ULTRALOW", "Ultralow")
 
 
 def test_label_merge_on_device(gpu):
@@ -605,3 +605,283 @@ def test_multi_rank_bench_matches_single_rank(gpu):
     assert d1["labels_sha256"] == d2["labels_sha256"]
     for d in (d1, d2):
         assert d["metric"].startswith("aligned pairs/sec") and d["unit"] == "pairs/s" and "roofline" in d
+
+
+# --------------------------------------------------------------------------- round 2: raw-byte alphabets
+ALPHA_CASES = {
+    # N runs and an IUPAC code: 4-bit symbol buffer; the reference unites N~N (byte equality, seqrush.rs:1269-1283)
+    "n-runs": lambda: [(n, (s[:200] + b"N" * 37 + s[237:600] + b"R" + s[601:]) if i % 2 == 0 else s[:300] + b"NNNN" + s[304:])
+                       for i, (n, s) in enumerate(synth.snp_family(5, 900, 0.04, 601))],
+    # soft-masked (lower-case) stretches: 'a' != 'A' forward, but the reverse complement maps both to 'T' (seqrush.rs:1166-1170)
+    "soft-masked": lambda: [(n, s[:150] + s[150:420].lower() + s[420:]) if i % 2 else (n, s) for i, (n, s) in
+                            enumerate(synth.snp_family(4, 800, 0.05, 602))],
+    "soft-masked-rc": lambda: [(n, synth.reverse_complement(s)) if i == 2 else (n, s[:100].lower() + s[100:]) if i == 1 else (n, s)
+                               for i, (n, s) in enumerate(synth.snp_family(4, 700, 0.04, 603))],
+    # lower-case + N + reverse-complemented member + indels
+    "mixed-indel-rc": lambda: [(n, (synth.reverse_complement(s) if i == 3 else s).replace(b"ACG", b"acg", 7).replace(b"TTA", b"TNA", 3))
+                               for i, (n, s) in enumerate(synth.indel_family(4, 600, 0.04, 0.03, 604))],
+    # more than 16 distinct bytes: 8-bit symbol buffer (raw bytes)
+    "iupac-8bit": lambda: [(n, s[:50] + b"RYSWKMBDHVNryswkmbdhvn" + s[72:400] + s[400:].lower()) if i < 2 else (n, s)
+                           for i, (n, s) in enumerate(synth.snp_family(3, 500, 0.05, 605))],
+}
+
+
+@pytest.mark.parametrize("name", sorted(ALPHA_CASES))
+def test_raw_byte_alphabets(gpu, name):
+    """bytes outside upper-case ACGT (N, IUPAC, soft-masked lower case) are compared raw like the reference does
+    (src/seqrush.rs:1162-1176, 1268-1283), incl. the lower-case asymmetry of the reverse complement: CIGARs, strands,
+    partition and GFA equal the oracle's"""
+    recs = ALPHA_CASES[name]()
+    al, labels, cnt = check_parity(recs)
+    ss = SeqSet(recs); ctx = Context(0); ctx.load(ss, Params())
+    rep = ctx.workspace_report(); ctx.close()
+    assert rep["symbol_bits"] == (8 if name == "iupac-8bit" else 4)
+    check_parity(recs, min_match_len=5)
+
+
+def test_raw_byte_alphabet_on_fallback_kernel_and_in_kernel_orientation(gpu, monkeypatch):
+    recs = ALPHA_CASES["mixed-indel-rc"]()
+    _, _, cnt = check_parity(recs, scores="0,4,6,2,24,1")          # no blocked instance: sr_align_bfs_kernel, 4-bit build
+    assert cnt["align_kernel"] == "sr_align_bfs_kernel"
+    monkeypatch.setenv("SR_PREORIENT", "0")                        # orientation inside the blocked kernel: the copy reload path
+    check_parity(recs)
+    check_parity(ALPHA_CASES["soft-masked-rc"]())
+
+
+# --------------------------------------------------------------------------- round 2: batches, explicit pair lists
+def test_batched_cigar_arena(gpu, monkeypatch):
+    """a shard whose worst-case CIGARs do not fit the arena runs in batches that reuse it: same partition, same
+    alignments (sr_ctx_run / sr_ctx_align_all), and the split-phase API refuses instead of returning stale CIGARs"""
+    recs = synth.snp_family(6, 500, 0.05, 611, rc_every=3)
+    ss, al1, labels1, _, _ = run_gpu(recs)
+    monkeypatch.setenv("SR_CIGAR_ARENA_OPS", "4100")               # ~4 pairs of (500 + 500 + 2) ops per batch
+    ctx = Context(0); ctx.load(ss, Params())
+    assert ctx.num_batches >= 8 and ctx.workspace_report()["batches"] == ctx.num_batches
+    with pytest.raises(sa.SeqRushError):
+        ctx.align()
+    ctx.run(); ctx.sync()
+    assert np.array_equal(ctx.download_labels(), labels1)
+    sc, rv, co = ctx.pair_results()
+    assert np.array_equal(sc, al1.score) and np.array_equal(rv, al1.is_reverse)
+    with pytest.raises(sa.SeqRushError):
+        ctx.alignments()
+    ctx.reset_uf()
+    al2 = ctx.align_all(unite=True); ctx.sync()
+    assert al2.n == al1.n and all(al2.cigar(i) == al1.cigar(i) for i in range(al1.n))
+    assert np.array_equal(ctx.download_labels(), labels1)
+    assert ctx.kernel_ms(0) > 0 and ctx.kernel_ms(1) > 0
+    ctx.close()
+    # Seam 1 through the batches
+    out = sa.create_aligner("allwave").align_sequences([sa.AlignmentSequence(n, s) for n, s in recs])
+    assert [r.cigar for r in out] == [al1.cigar(i) for i in range(al1.n)]
+
+
+def test_explicit_pair_list(gpu):
+    recs = synth.indel_family(5, 700, 0.04, 0.02, 621)
+    pairs = [(0, 1), (3, 2), (4, 4), (1, 0), (2, 4)]
+    ss = SeqSet(recs); ctx = Context(0); ctx.load_pairs(ss, Params(), pairs)
+    assert ctx.pairs() == pairs
+    ctx.run(); ctx.sync()
+    al = ctx.alignments(); labels = ctx.download_labels(); ctx.close()
+    o = ob.OracleSeqRush(records=recs)
+    op = ob.default_params()
+    for i, (q, t) in enumerate(pairs):
+        assert al.raw_cigar_bytes(i) == o.align_pair(op, q, t)["cigar"]
+    o.align_and_unite_list(op, pairs)
+    assert np.array_equal(labels, o.canonical_labels())
+    with pytest.raises(sa.SeqRushError):
+        Context(0).load_pairs(ss, Params(), [(0, 9)])
+
+
+def test_label_exchange_u32(gpu):
+    """u32 labels while 2N+2 < 2^32 -- the merged forest equals the 64-bit exchange's"""
+    import torch
+    recs = synth.snp_family(6, 300, 0.05, 631, rc_every=3)
+    ss = SeqSet(recs)
+    labs, ctxs = [], []
+    for r in range(2):
+        p = Params(); p.c.shard_rank, p.c.shard_count = r, 2
+        c = Context(0); c.load(ss, p); c.run(); c.sync()
+        t = torch.empty(c.uf_size, dtype=torch.int32, device="cuda")
+        c.labels_device_u32(t.data_ptr()); c.sync()
+        labs.append(t); ctxs.append(c)
+    gathered = torch.cat(labs); torch.cuda.synchronize()
+    ctxs[0].merge_labels_u32(gathered.data_ptr(), 2); ctxs[0].sync()
+    o = ob.OracleSeqRush(records=recs)
+    o.align_and_unite(ob.default_params())
+    assert np.array_equal(ctxs[0].download_labels(), o.canonical_labels())
+    assert sorted(ctxs[0].pairs() + ctxs[1].pairs()) == sorted((q, t) for q in range(6) for t in range(6))
+    for c in ctxs:
+        c.close()
+
+
+# --------------------------------------------------------------------------- round 2: sparsification (SURVEY 8f-2)
+@pytest.mark.parametrize("spec", ["tree:2,1,0.1", "tree:3,3,0.1,12", "tree:1", "tree:0,2,0.0,8", "connectivity:0.9", "auto",
+                                  "random:0.4"])
+def test_sparsified_pair_lists_match_oracle(gpu, spec):
+    """k-mer sketches / k-nearest / k-farthest selection on the device give the oracle's pair list (own definition of
+    allwave's absent rules: unpinned), and the partition over exactly that list equals the oracle's"""
+    fam = synth.snp_family(5, 600, 0.03, 641) + synth.snp_family(5, 600, 0.03, 642) + synth.snp_family(4, 500, 0.10, 643, rc_every=2)
+    recs = [(f"s{i}", s) for i, (_, s) in enumerate(fam)] + [("tiny", b"ACGTAC"), ("n", b"ACGTNNNNNNNNNNNNNNNNNNNNACGTTGCAACGT" * 6)]
+    ss = SeqSet(recs); ctx = Context(0); ctx.load(ss, Params(sparsification=spec))
+    pairs = ctx.pairs()
+    o = ob.OracleSeqRush(records=recs)
+    assert pairs == o.sparsified_pairs(spec)
+    assert all((q, q) in set(pairs) for q in range(len(recs)))
+    ctx.run(); ctx.sync(); labels = ctx.download_labels(); ctx.close()
+    op = ob.default_params(); op.threads = 8
+    o.align_and_unite_list(op, pairs)
+    assert np.array_equal(labels, o.canonical_labels())
+    if spec.startswith("tree:3"):
+        assert len(pairs) < len(recs) ** 2
+
+
+def test_config_c4_scaled_parity(gpu):
+    """BASELINE.json configs[3] scaled to 96 x 2 kb (6 clades): tree:3,3,0.1 pair list, per-pair results and the
+    partition equal the oracle's"""
+    recs = synth.config_c4(96, 2000, clades=6)
+    ss = SeqSet(recs); ctx = Context(0); ctx.load(ss, Params(sparsification="tree:3,3,0.1"))
+    pairs = ctx.pairs()
+    o = ob.OracleSeqRush(records=recs)
+    assert pairs == o.sparsified_pairs("tree:3,3,0.1")
+    assert 96 + 2 * 96 * 3 <= len(pairs) < 96 * 96 // 2
+    al = ctx.align_all(unite=True); ctx.sync(); labels = ctx.download_labels(); ctx.close()
+    op = ob.default_params(); op.threads = 8
+    for i in range(0, al.n, 9):
+        q, t = pairs[i]
+        assert al.raw_cigar_bytes(i) == o.align_pair(op, q, t)["cigar"]
+    o.align_and_unite_list(op, pairs)
+    assert np.array_equal(labels, o.canonical_labels())
+
+
+# --------------------------------------------------------------------------- round 2: BASELINE configs at size
+def _report(name, ctx, t_ms, extra=None):
+    """sizing + timing of a full-size run, kept under gpurun_out/ for DESIGN.md"""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    rec = {"config": name, "step_ms": t_ms, "workspace": ctx.workspace_report()}
+    rec.update(extra or {})
+    with open(os.path.join(root, "gpurun_out", f"fullsize_{name}.json"), "w") as fh:
+        json.dump(rec, fh)
+
+
+def test_c5_three_50kb_sequences_with_inversions_parity(gpu):
+    """BASELINE.json configs[4] per-pair behaviour at its real length: 50 kb (int32 rows, 4 x 12.5 KB of LDS), in-place
+    inversions of 3 kb and 1.5 kb, one sequence entirely reverse-complemented -- CIGARs, strands, scores,
+    partition and GFA equal the oracle's"""
+    fam = synth.indel_family_fast(3, 50000, 0.02, 0.001, 5101, max_indel=4)
+    s0 = fam[0][1]
+    s1 = synth.invert_segment(synth.invert_segment(fam[1][1], 12000, 3000), 30000, 1500)
+    s2 = synth.reverse_complement(fam[2][1])
+    recs = [("plain", s0), ("inverted", s1), ("rc", s2)]
+    al, labels, cnt = check_parity(recs)
+    rev = {(int(al.query_idx[i]), int(al.target_idx[i])): bool(al.is_reverse[i]) for i in range(al.n)}
+    assert rev[(2, 0)] and rev[(0, 2)] and rev[(2, 1)] and not rev[(0, 1)] and not rev[(2, 2)]
+    assert max(int(x) for x in al.score) > 10000
+
+
+def test_full_size_c3_surrogate_parity(gpu):
+    """BASELINE.json configs[2] surrogate at SURVEY 8(d)'s size (12 x ~14 kb, 3 % substitutions, indels, 200-800 bp
+    insertions; the real HLA-zoo DRB1 set is not in the container): all 144 CIGARs, the partition and the GFA equal
+    the oracle's; every path re-spells its input"""
+    import time
+    recs = synth.config_c3_surrogate()
+    al, labels, cnt = check_parity(recs)
+    assert al.n == 144
+    ss = SeqSet(recs); ctx = Context(0); ctx.load(ss, Params())
+    t0 = time.perf_counter(); ctx.run(); ctx.sync(); dt = (time.perf_counter() - t0) * 1e3
+    gfa, nn, ne = ctx.build_gfa()
+    _report("C3", ctx, dt, {"pairs": 144, "nodes": nn, "edges": ne, "align_ms": ctx.kernel_ms(0)})
+    ctx.close()
+    seg = {}
+    for l in gfa.split("\n"):
+        if l.startswith("S\t"):
+            f = l.split("\t"); seg[f[1]] = f[2]
+        elif l.startswith("P\t"):
+            f = l.split("\t")
+            assert "".join(seg[s[:-1]] for s in f[2].split(",")) == dict(recs)[f[1]].decode()
+
+
+def _component_bases_consistent(recs, labels):
+    comp = np.zeros(256, dtype=np.uint8)
+    for a, b in (b"AT", b"TA", b"CG", b"GC"):
+        comp[a] = b
+    bases = np.frombuffer(b"".join(s for _, s in recs), dtype=np.uint8)
+    lab_base = bases[(labels[: 2 * len(bases)] >> np.uint64(1)).astype(np.int64)]
+    own = np.repeat(bases, 2)
+    return bool(np.all((lab_base == own) | (lab_base == comp[own])))
+
+
+def test_full_size_c4_properties(gpu):
+    """BASELINE.json configs[3] at full size: 1024 x 2 kb, -x tree:3,3,0.1.  The pair list equals the oracle's; a sample
+    of pairs equals the oracle bit for bit; size-independent properties over the whole run"""
+    import time
+    recs = synth.config_c4()
+    ss = SeqSet(recs); ctx = Context(0)
+    t0 = time.perf_counter(); ctx.load(ss, Params(sparsification="tree:3,3,0.1")); t_load = (time.perf_counter() - t0) * 1e3
+    pairs = ctx.pairs()
+    o = ob.OracleSeqRush(records=recs)
+    assert pairs == o.sparsified_pairs("tree:3,3,0.1")
+    assert 1024 + 2 * 1024 * 3 <= len(pairs) < 1024 * 1024 // 4
+    t0 = time.perf_counter(); ctx.run(); ctx.sync(); dt = (time.perf_counter() - t0) * 1e3
+    sc, rv, co = ctx.pair_results()
+    labels = ctx.download_labels()
+    gfa, nn, ne = ctx.build_gfa()
+    _report("C4", ctx, dt, {"pairs": len(pairs), "load_ms_incl_sketches": t_load, "nodes": nn, "edges": ne,
+                            "align_ms": ctx.kernel_ms(0), "orient_ms": ctx.kernel_ms(4), "unite_ms": ctx.kernel_ms(1)})
+    ctx.close()
+    d = {p: int(s) for p, s in zip(pairs, sc)}
+    assert all(s >= 0 for s in d.values()) and all(d[(q, q)] == 0 for q in range(1024))
+    assert all(d[(t, q)] == s for (q, t), s in d.items()) and not rv.any()
+    assert _component_bases_consistent(recs, labels) and nn < 2048 * 1024
+    # sampled pairs through an explicit list: same scores as in the full run, CIGARs equal the oracle's
+    sample = pairs[5::997][:40]
+    c2 = Context(0); c2.load_pairs(ss, Params(), sample); c2.run(); c2.sync(); al = c2.alignments(); c2.close()
+    op = ob.default_params()
+    for i, (q, t) in enumerate(sample):
+        assert int(al.score[i]) == d[(q, t)]
+        assert al.raw_cigar_bytes(i) == o.align_pair(op, q, t)["cigar"]
+    seg = {}
+    names = dict(recs)
+    for l in gfa.split("\n"):
+        if l.startswith("S\t"):
+            f = l.split("\t"); seg[f[1]] = f[2]
+        elif l.startswith("P\t") and l.split("\t", 2)[1] in ("seq0", "seq77", "seq1023"):
+            f = l.split("\t")
+            assert "".join(seg[s[:-1]] if s[-1] == "+" else synth.reverse_complement(seg[s[:-1]].encode()).decode()
+                           for s in f[2].split(",")) == names[f[1]].decode()
+
+
+def test_full_size_c5_properties(gpu):
+    """BASELINE.json configs[4] at full size on one GPU: 256 x 50 kb with inversions, 65 536 ordered pairs, int32 rows.
+    Size-independent properties: every score >= 0 and symmetric, self pairs 0, strands symmetric and exactly the
+    reverse-complemented inputs flip, components hold one base letter up to complement; a sample of pairs re-run
+    through an explicit list gives the same scores and CIGARs that cost their score"""
+    import time
+    recs = synth.config_c5()
+    n = len(recs)
+    ss = SeqSet(recs); ctx = Context(0); ctx.load(ss, Params())
+    assert ctx.num_pairs == n * n
+    t0 = time.perf_counter(); ctx.run(); ctx.sync(); dt = (time.perf_counter() - t0) * 1e3
+    sc, rv, co = ctx.pair_results()
+    labels = ctx.download_labels()
+    cnt = ctx.counters()
+    _report("C5", ctx, dt, {"pairs": n * n, "align_ms": ctx.kernel_ms(0), "orient_ms": ctx.kernel_ms(4),
+                            "unite_ms": ctx.kernel_ms(1), "wf_cells": cnt["wf_cells"], "max_score": int(sc.max()),
+                            "mean_score": float(sc.mean())})
+    ctx.close()
+    S = sc.reshape(n, n); R = rv.reshape(n, n)
+    assert (S >= 0).all() and (np.diag(S) == 0).all() and (S == S.T).all() and (R == R.T).all()
+    # whole-sequence reverse complements (10 % of the inputs) are exactly the strand flips: R = f(q) xor f(t)
+    f = R[0] ^ R[0, 0]
+    assert f.any() and not f.all() and (R == (f[:, None] ^ f[None, :])).all()
+    assert _component_bases_consistent(recs, labels)
+    r, pen = ob.parse_scores("0,5,8,2,24,1")
+    order = np.argsort(S, axis=None)
+    sample = [(int(i) // n, int(i) % n) for i in list(order[-3:]) + list(order[n + 3: n + 6]) + list(order[::9973][:10])]
+    c2 = Context(0); c2.load_pairs(ss, Params(), sample); c2.run(); c2.sync(); al = c2.alignments(); c2.close()
+    for i, (q, t) in enumerate(sample):
+        assert int(al.score[i]) == int(S[q, t]) and bool(al.is_reverse[i]) == bool(R[q, t])
+        qs = synth.reverse_complement(recs[q][1]) if al.is_reverse[i] else recs[q][1]
+        assert ob.cigar_score(al.raw_cigar_bytes(i), qs, recs[t][1], pen) == int(S[q, t])

@@ -25,7 +25,7 @@ def test_every_declared_symbol_is_exported():
     missing = [s for s in sorted(declared) if not hasattr(L, s)]
     assert not missing, missing
     assert declared == set(_lib.EXPORTS)
-    assert L.sr_abi_version() == 1
+    assert L.sr_abi_version() == 2
 
 
 def test_no_device_fails_loudly():
@@ -91,6 +91,52 @@ def test_pair_list_and_sharding():
     assert all((q, q) in sub for q in range(20))
     assert 0.15 < (len(sub) - 20) / 380 < 0.45
     assert sub == pair_list(20, p)        # deterministic
+
+
+def test_sparsified_pair_lists_host_kinds_match_oracle():
+    """connectivity / auto / random need no sketches: the product's host enumeration equals the oracle's restatement
+    of the same (own, unpinned) definition; tree needs the sequences and is refused by the host-only helper"""
+    for n in (3, 9, 10, 37):
+        recs = [(f"s{i}", b"ACGT" * 3) for i in range(n)]
+        o = ob.OracleSeqRush(records=recs)
+        for spec in ("none", "auto", "connectivity:0.5", "connectivity:0.999", "connectivity:1.0", "random:0.25", "0.7"):
+            for ex in (0, 1):
+                p = Params(sparsification=spec)
+                p.c.exclude_self = ex
+                assert pair_list(n, p) == o.sparsified_pairs(spec, exclude_self=bool(ex)), (n, spec, ex)
+    p = Params(sparsification="connectivity:0.5")
+    got = pair_list(200, p)
+    assert all((t, q) in set(got) for q, t in got)                  # both directions of a kept unordered pair
+    assert 200 < len(got) < 200 * 200 // 4                          # (ln 200 + 0.37) / 200 = 2.8 % of the pairs
+    with pytest.raises(sa.SeqRushError) as e:
+        pair_list(5, Params(sparsification="tree:3,3,0.1"))
+    assert e.value.code == -6
+    for spec, want in [("tree:3", (3, 0, 0.0, 16)), ("tree:3,2", (3, 2, 0.0, 16)), ("tree:1,0,0.25", (1, 0, 0.25, 16)),
+                       ("tree:4,4,1.0,21", (4, 4, 1.0, 21))]:
+        p = Params(sparsification=spec)
+        sp = ob.Sparsification(); assert ob.lib().sro_parse_sparsification(spec.encode(), C.byref(sp)) == 0
+        assert (p.c.tree_k_nearest, p.c.tree_k_farthest, p.c.tree_rand_frac, p.c.tree_kmer) == want
+        assert (sp.k_nearest, sp.k_farthest, sp.rand_frac, sp.kmer_size) == want
+    for bad in ("tree:a", "tree:1,b", "tree:1,1,1.5", "tree:1,1,0.1,0", "tree:1,2,3,4,5"):
+        with pytest.raises(sa.SeqRushError):
+            Params(sparsification=bad)
+
+
+def test_shards_partition_the_list_for_every_world_size():
+    for world in (1, 2, 3, 4, 8):
+        for spec in ("none", "connectivity:0.6"):
+            shards = []
+            for r in range(world):
+                p = Params(sparsification=spec); p.c.shard_rank, p.c.shard_count = r, world
+                shards.append(pair_list(23, p))
+            full = pair_list(23, Params(sparsification=spec))
+            assert sorted(sum(shards, [])) == sorted(full)
+            assert all(s == sorted(s) for s in shards)              # a rank keeps enumeration order
+            off = [sum(1 for q, t in s if q != t) for s in shards]
+            assert max(off) - min(off) <= 1                         # equal costs: round-robin; self pairs spread apart
+            slf = [sum(1 for q, t in s if q == t) for s in shards]
+            cost = [4 * a + 2 * b for a, b in zip(off, slf)]            # |q||t| for pairs, |q| for self pairs (len 2 here)
+            assert max(cost) - min(cost) <= 4 and max(slf) - min(slf) <= 3
 
 
 def test_fasta_loader_mirror(tmp_path):
