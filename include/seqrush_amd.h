@@ -235,6 +235,12 @@ int sr_ctx_counters_ext(sr_ctx *c, uint64_t out[32]);
  * canonical labels.  Returns malloc'd text in *gfa (free with sr_free). */
 int sr_build_gfa(const sr_seqset *seqs, const uint64_t *labels, char **gfa,
                  uint64_t *n_nodes, uint64_t *n_edges);
+/* the same with the reference's post-induction step for `--no-sort` without `--no-compact`
+ * (src/bidirected_gfa_writer.rs:39-51): compact() merges linear chains of perfect neighbours round after round
+ * (src/bidirected_ops.rs:91-490), renumber_nodes_sequentially() (:75-89); compact == 0 is sr_build_gfa */
+int sr_build_gfa_opts(const sr_seqset *seqs, const uint64_t *labels, int compact, char **gfa,
+                      uint64_t *n_nodes, uint64_t *n_edges);
+int sr_ctx_build_gfa_opts(sr_ctx *c, const sr_seqset *seqs, int compact, char **gfa, uint64_t *n_nodes, uint64_t *n_edges);
 void sr_free(void *p);
 
 const char *sr_last_error(void);

@@ -206,6 +206,10 @@ int sro_sparsified_pairs(const sro_seqrush *s, const sro_sparsification *sp, uin
  * Returns malloc'd GFA text. */
 char *sro_build_gfa(sro_seqrush *s, int canonical, int faithful_scan,
                     uint64_t *n_nodes, uint64_t *n_edges);
+/* compact() + renumber_nodes_sequentially() (src/bidirected_ops.rs:75-490) on a --no-compact GFA text as
+ * sro_build_gfa writes it: the graph the reference writes for --no-sort without --no-compact
+ * (src/bidirected_gfa_writer.rs:39-51).  Literal restatement, quadratic: test-sized graphs only.  malloc'd text. */
+char *sro_compact_gfa(const char *gfa, uint64_t *n_nodes, uint64_t *n_edges);
 /* canonical min-Pos label per element of the UF (len = uf size) */
 void sro_canonical_labels(sro_seqrush *s, uint64_t *labels);
 

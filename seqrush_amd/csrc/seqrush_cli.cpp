@@ -1,7 +1,7 @@
 // seqrush_cli.cpp -- C++ host side above the C ABI: the reference's CLI surface for the hot path
 // (src/main.rs:4-7, Args src/seqrush.rs:17-152, run_seqrush :1839-1853, load_sequences :1801-1837).
-// Everything that computes goes through include/seqrush_amd.h; only --no-sort --no-compact output
-// exists (compaction and the Ygs sort are outside the hot path).
+// Everything that computes goes through include/seqrush_amd.h; output is the --no-sort graph, compacted unless
+// --no-compact (the Ygs layout is outside the hot path).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -42,7 +42,7 @@ static bool load_sequences(const std::string &path, std::vector<Seq> &out) {
 
 static void usage() {
     fprintf(stderr, "usage: seqrush_mi355x -s in.fa [-o output.gfa] [-k 0] [-S 0,5,8,2,24,1] [--orientation-scores 0,1,1,1]\n"
-                    "       [-d max_divergence] [-x none|random:F] [-p in.paf] [--output-alignments out.paf] --no-sort --no-compact [--device N]\n");
+                    "       [-d max_divergence] [-x none|auto|random:F|connectivity:P|tree:kn[,kf[,rf[,k]]]] [-p in.paf] [--output-alignments out.paf] --no-sort [--no-compact] [--device N]\n");
 }
 
 int main(int argc, char **argv) {
@@ -77,7 +77,7 @@ int main(int argc, char **argv) {
     }
     if (sequences.empty()) { usage(); return 2; }
     if (aligner != "allwave" && aligner != "AllWave") { fprintf(stderr, "Error: aligner '%s' is out of scope; only 'allwave'\n", aligner.c_str()); return 1; }
-    if (!(no_sort && no_compact)) { fprintf(stderr, "Error: only --no-sort --no-compact output is implemented\n"); return 1; }
+    if (!no_sort) { fprintf(stderr, "Error: only --no-sort output is implemented (the Ygs layout is outside the hot path); compaction runs unless --no-compact\n"); return 1; }
     std::vector<Seq> seqs;
     if (!load_sequences(sequences, seqs)) { fprintf(stderr, "Error: cannot read %s\n", sequences.c_str()); return 1; }
     printf("Loaded %zu sequences\n", seqs.size());
@@ -118,7 +118,7 @@ int main(int argc, char **argv) {
     if (sr_ctx_sync(ctx)) return die();
     char *gfa = nullptr;
     uint64_t nn = 0, ne = 0;
-    if (sr_ctx_build_gfa(ctx, &set, &gfa, &nn, &ne)) return die();
+    if (sr_ctx_build_gfa_opts(ctx, &set, no_compact ? 0 : 1, &gfa, &nn, &ne)) return die();   // compact + renumber unless --no-compact
     sr_ctx_destroy(ctx);
     std::ofstream o(output, std::ios::binary);
     o << gfa;

@@ -18,6 +18,7 @@
 #include <vector>
 #include "../../include/seqrush_amd.h"
 #include "sr_internal.h"
+#include "sr_graph.h"
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -1415,95 +1416,69 @@ extern "C" int sr_write_paf(const sr_alignments *a, const sr_seqset *seqs, const
 // :154-157), node base = base at offset(label) (:176-182), step reversed iff
 // node base and sequence base are complementary (:190-203), edges deduplicated
 // against themselves and their complement, first orientation kept
-// (bidirected_ops.rs:813-825); write_gfa layout bidirected_ops.rs:880-925.
+// (bidirected_ops.rs:813-825); optional compact() + renumber (sr_compact.cpp); write_gfa layout
+// bidirected_ops.rs:880-925.
 struct PairHash {
     size_t operator()(const std::pair<uint64_t, uint64_t> &p) const {
         return (size_t)splitmix64(p.first * 0x9e3779b97f4a7c15ULL ^ p.second);
     }
 };
 
-// write_gfa layout (src/bidirected_ops.rs:880-925) from compact arrays: node_base[id-1], step(g) = id<<1|rev,
-// edge(i) = (from, to) handles in first-seen order
-template <typename StepFn, typename EdgeFn>
-static char *format_gfa(const sr_seqset *seqs, uint64_t n_nodes, const uint8_t *node_base, StepFn step, uint64_t n_edges,
-                        EdgeFn edge) {
-    const uint64_t N = seqs->offsets[seqs->n];
-    std::string out;
-    out.reserve(N * 8 + 64);
-    out += "H\tVN:Z:1.0\n";
-    char tmp[96];
-    for (uint64_t id = 1; id <= n_nodes; id++) {
-        snprintf(tmp, sizeof(tmp), "S\t%llu\t%c\n", (unsigned long long)id, (char)node_base[id - 1]);
-        out += tmp;
-    }
-    for (uint64_t i = 0; i < n_edges; i++) {
-        const std::pair<uint64_t, uint64_t> e = edge(i);
-        snprintf(tmp, sizeof(tmp), "L\t%llu\t%c\t%llu\t%c\t0M\n", (unsigned long long)(e.first >> 1),
-                 (e.first & 1) ? '-' : '+', (unsigned long long)(e.second >> 1), (e.second & 1) ? '-' : '+');
-        out += tmp;
-    }
-    for (uint32_t s = 0; s < seqs->n; s++) {
-        out += "P\t"; out += seqs->names[s]; out += "\t";
-        for (uint64_t g = seqs->offsets[s]; g < seqs->offsets[s + 1]; g++) {
-            if (g != seqs->offsets[s]) out += ',';
-            const uint64_t st = step(g);
-            snprintf(tmp, sizeof(tmp), "%llu%c", (unsigned long long)(st >> 1), (st & 1) ? '-' : '+');
-            out += tmp;
-        }
-        out += "\t*\n";
-    }
-    char *res = (char *)malloc(out.size() + 1);
-    memcpy(res, out.c_str(), out.size() + 1);
-    return res;
+static char *finish_gfa(SrGraph &g, const sr_seqset *seqs, int compact, uint64_t *n_nodes, uint64_t *n_edges) {
+    if (compact) { sr_graph_compact(g); sr_graph_renumber(g); }     // src/bidirected_gfa_writer.rs:39-51
+    return sr_graph_format_gfa(g, seqs->names, n_nodes, n_edges);
 }
 
-extern "C" int sr_build_gfa(const sr_seqset *seqs, const uint64_t *labels, char **gfa,
-                            uint64_t *n_nodes, uint64_t *n_edges) {
+extern "C" int sr_build_gfa_opts(const sr_seqset *seqs, const uint64_t *labels, int compact, char **gfa,
+                                 uint64_t *n_nodes, uint64_t *n_edges) {
     if (!seqs || !labels || !gfa || !seqs->names) return fail(SR_ERR_INVALID, "null argument");
     const uint64_t N = seqs->offsets[seqs->n];
+    if (N >= 0x7fffffffULL) return fail(SR_ERR_UNSUPPORTED, "graph induction supports < 2^31 bases");
     const uint64_t ufn = 2 * N + 2;
-    std::vector<uint64_t> node_of(ufn, 0);
-    std::vector<uint8_t> node_base(1, 0);
-    std::vector<uint64_t> steps(N);
-    uint64_t next_id = 1;
+    std::vector<uint32_t> node_of(ufn, 0);
+    SrGraph g;
+    g.node_seq.assign(1, std::string()); g.node_alive.assign(1, 0);
+    g.steps.resize(N); g.path_off.assign(1, 0);
+    uint32_t next_id = 1;
     for (uint32_t s = 0; s < seqs->n; s++) {
-        for (uint64_t g = seqs->offsets[s]; g < seqs->offsets[s + 1]; g++) {
-            const uint64_t lf = labels[g << 1], lr = labels[(g << 1) | 1];
+        for (uint64_t p = seqs->offsets[s]; p < seqs->offsets[s + 1]; p++) {
+            const uint64_t lf = labels[p << 1], lr = labels[(p << 1) | 1];
             if (lf >= ufn || lr >= ufn) return fail(SR_ERR_INVALID, "label out of range");
-            uint64_t rep = node_of[lf] ? lf : (node_of[lr] ? lr : lf);
-            uint64_t id = node_of[rep];
+            const uint64_t rep = node_of[lf] ? lf : (node_of[lr] ? lr : lf);
+            uint32_t id = node_of[rep];
             if (!id) {
                 id = next_id++;
                 node_of[rep] = id;
                 const uint64_t off = rep >> 1;
-                node_base.push_back(off < N ? seqs->bases[off] : seqs->bases[g]);
+                g.node_seq.push_back(std::string(1, (char)(off < N ? seqs->bases[off] : seqs->bases[p])));
+                g.node_alive.push_back(1);
             }
-            const uint8_t nb = (uint8_t)toupper(node_base[id]), eb = (uint8_t)toupper(seqs->bases[g]);
+            const uint8_t nb = (uint8_t)toupper((unsigned char)g.node_seq[id][0]), eb = (uint8_t)toupper(seqs->bases[p]);
             const bool rev = (nb == 'A' && eb == 'T') || (nb == 'T' && eb == 'A') ||
                              (nb == 'C' && eb == 'G') || (nb == 'G' && eb == 'C');
-            steps[g] = (id << 1) | (rev ? 1 : 0);
+            g.steps[p] = (id << 1) | (rev ? 1u : 0u);
         }
+        g.path_off.push_back(seqs->offsets[s + 1]);
     }
     std::unordered_set<std::pair<uint64_t, uint64_t>, PairHash> eset;
-    std::vector<std::pair<uint64_t, uint64_t>> eorder;
     eset.reserve(N);
     for (uint32_t s = 0; s < seqs->n; s++)
-        for (uint64_t g = seqs->offsets[s]; g + 1 < seqs->offsets[s + 1]; g++) {
-            const uint64_t from = steps[g], to = steps[g + 1];
-            if (eset.count({from, to}) || eset.count({to ^ 1, from ^ 1})) continue;
+        for (uint64_t p = seqs->offsets[s]; p + 1 < seqs->offsets[s + 1]; p++) {
+            const uint32_t from = g.steps[p], to = g.steps[p + 1];
+            if (eset.count({from, to}) || eset.count({to ^ 1u, from ^ 1u})) continue;
             eset.insert({from, to});
-            eorder.push_back({from, to});
+            g.edges.push_back({from, to});
         }
-    *gfa = format_gfa(seqs, next_id - 1, node_base.data() + 1, [&](uint64_t g) { return steps[g]; }, eorder.size(),
-                      [&](uint64_t i) { return eorder[i]; });
-    if (n_nodes) *n_nodes = next_id - 1;
-    if (n_edges) *n_edges = eorder.size();
+    *gfa = finish_gfa(g, seqs, compact, n_nodes, n_edges);
     return SR_OK;
+}
+extern "C" int sr_build_gfa(const sr_seqset *seqs, const uint64_t *labels, char **gfa, uint64_t *n_nodes, uint64_t *n_edges) {
+    return sr_build_gfa_opts(seqs, labels, 0, gfa, n_nodes, n_edges);
 }
 
 // graph induction on the device from the context's union-find (sr_graph.hip); same
 // text as sr_build_gfa() on the downloaded canonical labels.  which = 3 of sr_ctx_kernel_ms times it.
-extern "C" int sr_ctx_build_gfa(sr_ctx *c, const sr_seqset *seqs, char **gfa, uint64_t *n_nodes, uint64_t *n_edges) {
+extern "C" int sr_ctx_build_gfa_opts(sr_ctx *c, const sr_seqset *seqs, int compact, char **gfa, uint64_t *n_nodes, uint64_t *n_edges) {
     if (!c || !c->loaded) return fail(SR_ERR_INVALID, "context not loaded");
     if (!seqs || !gfa || !seqs->names) return fail(SR_ERR_INVALID, "null argument");
     const uint64_t N = seqs->offsets[seqs->n];
@@ -1519,14 +1494,16 @@ extern "C" int sr_ctx_build_gfa(sr_ctx *c, const sr_seqset *seqs, char **gfa, ui
     const uint64_t ntiles = (N + 1023) / 1024 + 1;
     struct Tmp { std::vector<void *> v; ~Tmp() { for (void *p : v) (void)hipFree(p); } } tmp;
     auto dalloc = [&](size_t bytes) -> void * { void *p = nullptr; if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr; tmp.v.push_back(p); return p; };
-    uint8_t *d_bases = (uint8_t *)dalloc(N), *d_islast = (uint8_t *)dalloc(N), *d_nbase = (uint8_t *)dalloc(N);
+    uint8_t *d_bases = c->d_bases, *d_islast = (uint8_t *)dalloc(N), *d_nbase = (uint8_t *)dalloc(N);
+    bool own_bases = false;
+    if (!d_bases) { d_bases = (uint8_t *)dalloc(N); own_bases = true; }        // (PAF contexts keep no byte copy)
     uint32_t *d_flag = (uint32_t *)dalloc(N * 4), *d_nid = (uint32_t *)dalloc(N * 4), *d_steps = (uint32_t *)dalloc((N + 1) * 4);
     uint32_t *d_eslot = (uint32_t *)dalloc(N * 4), *d_hvals = (uint32_t *)dalloc(hcap * 4), *d_tiles = (uint32_t *)dalloc(ntiles * 4);
     uint32_t *d_counts = (uint32_t *)dalloc(8);
     unsigned long long *d_hkeys = (unsigned long long *)dalloc(hcap * 8), *d_edges = (unsigned long long *)dalloc(N * 8);
     if (!d_bases || !d_islast || !d_nbase || !d_flag || !d_nid || !d_steps || !d_eslot || !d_hvals || !d_tiles || !d_counts ||
         !d_hkeys || !d_edges) return fail(SR_ERR_NOMEM, "not enough device memory for graph induction");
-    HIPCHK(hipMemcpyAsync(d_bases, seqs->bases, N, hipMemcpyHostToDevice, c->stream));
+    if (own_bases) HIPCHK(hipMemcpyAsync(d_bases, seqs->bases, N, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(d_islast, islast.data(), N, hipMemcpyHostToDevice, c->stream));
     hipEvent_t *ge0, *ge1;
     if ((r = ev_get(c, 3, 0, &ge0, &ge1))) return r;
@@ -1541,15 +1518,22 @@ extern "C" int sr_ctx_build_gfa(sr_ctx *c, const sr_seqset *seqs, char **gfa, ui
     uint32_t counts[2] = {0, 0};
     HIPCHK(hipMemcpy(counts, d_counts, 8, hipMemcpyDeviceToHost));
     std::vector<uint8_t> nbase(counts[0] ? counts[0] : 1);
-    std::vector<uint32_t> steps(N);
     std::vector<unsigned long long> edges(counts[1] ? counts[1] : 1);
+    SrGraph g;
+    g.steps.resize(N);
     HIPCHK(hipMemcpy(nbase.data(), d_nbase, counts[0], hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(steps.data(), d_steps, N * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(g.steps.data(), d_steps, N * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(edges.data(), d_edges, (size_t)counts[1] * 8, hipMemcpyDeviceToHost));
-    *gfa = format_gfa(seqs, counts[0], nbase.data(), [&](uint64_t g) { return (uint64_t)steps[g]; }, counts[1],
-                      [&](uint64_t i) { return std::pair<uint64_t, uint64_t>(edges[i] >> 32, edges[i] & 0xffffffffULL); });
-    if (n_nodes) *n_nodes = counts[0];
-    if (n_edges) *n_edges = counts[1];
+    g.node_seq.assign((size_t)counts[0] + 1, std::string()); g.node_alive.assign((size_t)counts[0] + 1, 1);
+    g.node_alive[0] = 0;
+    for (uint32_t i = 0; i < counts[0]; i++) g.node_seq[i + 1].assign(1, (char)nbase[i]);
+    g.path_off.assign(1, 0);
+    for (uint32_t s = 0; s < seqs->n; s++) g.path_off.push_back(seqs->offsets[s + 1]);
+    g.edges.resize(counts[1]);
+    for (uint32_t i = 0; i < counts[1]; i++) g.edges[i] = {(uint32_t)(edges[i] >> 32), (uint32_t)(edges[i] & 0xffffffffULL)};
+    *gfa = finish_gfa(g, seqs, compact, n_nodes, n_edges);
     return SR_OK;
 }
-
+extern "C" int sr_ctx_build_gfa(sr_ctx *c, const sr_seqset *seqs, char **gfa, uint64_t *n_nodes, uint64_t *n_edges) {
+    return sr_ctx_build_gfa_opts(c, seqs, 0, gfa, n_nodes, n_edges);
+}

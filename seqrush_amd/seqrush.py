@@ -32,8 +32,8 @@ class Args:
     sparsification: str = "none"            # -x
     paf: Optional[str] = None               # -p: replay alignments from a PAF file instead of aligning
     output_alignments: Optional[str] = None  # --output-alignments
-    no_compact: bool = True                 # only --no-compact is implemented
-    no_sort: bool = True                    # only --no-sort is implemented
+    no_compact: bool = False                # --no-compact (default: compact + renumber, bidirected_gfa_writer.rs:39-51)
+    no_sort: bool = True                    # only --no-sort is implemented (Ygs layout out of scope)
     aligner: str = "allwave"
     verbose: bool = False
     device: int = 0                         # added: HIP device ordinal
@@ -290,11 +290,13 @@ class Context:
         self.seqset = seqset
         check(self.L.sr_ctx_load_paf(self._h, C.byref(seqset.c), C.byref(params.c), paf_path.encode()))
 
-    def build_gfa(self):
-        """graph induction on the device from this context's union-find (SURVEY 8f rank 1) + GFA text;
-        -> (gfa_text, n_nodes, n_edges), byte-identical to build_gfa(seqset, download_labels())"""
+    def build_gfa(self, compact: bool = False):
+        """graph induction on the device from this context's union-find (+ compaction and
+        renumbering, src/bidirected_gfa_writer.rs:39-51) + GFA text;
+        -> (gfa_text, n_nodes, n_edges), byte-identical to build_gfa(seqset, download_labels(), compact)"""
         out = C.c_void_p(); nn = C.c_uint64(); ne = C.c_uint64()
-        check(self.L.sr_ctx_build_gfa(self._h, C.byref(self.seqset.c), C.byref(out), C.byref(nn), C.byref(ne)))
+        check(self.L.sr_ctx_build_gfa_opts(self._h, C.byref(self.seqset.c), 1 if compact else 0, C.byref(out),
+                                           C.byref(nn), C.byref(ne)))
         text = C.cast(out, C.c_char_p).value.decode()
         self.L.sr_free(out)
         return text, int(nn.value), int(ne.value)
@@ -383,14 +385,14 @@ class Context:
             pass
 
 
-def build_gfa(seqset: SeqSet, labels: np.ndarray):
-    """Graph induction + GFA text from canonical labels (consumer A9; --no-sort --no-compact).
+def build_gfa(seqset: SeqSet, labels: np.ndarray, compact: bool = False):
+    """Graph induction + GFA text from canonical labels (consumer A9; --no-sort, with or without --no-compact).
     -> (gfa_text, n_nodes, n_edges)"""
     L = _lib.load()
     labels = np.ascontiguousarray(labels, dtype=np.uint64)
     out = C.c_void_p(); nn = C.c_uint64(); ne = C.c_uint64()
-    check(L.sr_build_gfa(C.byref(seqset.c), labels.ctypes.data_as(C.POINTER(C.c_uint64)),
-                         C.byref(out), C.byref(nn), C.byref(ne)))
+    check(L.sr_build_gfa_opts(C.byref(seqset.c), labels.ctypes.data_as(C.POINTER(C.c_uint64)), 1 if compact else 0,
+                              C.byref(out), C.byref(nn), C.byref(ne)))
     text = C.cast(out, C.c_char_p).value.decode()
     L.sr_free(out)
     return text, int(nn.value), int(ne.value)
@@ -455,10 +457,11 @@ class SeqRush:
         self.write_gfa(args)
 
     def write_gfa(self, args: Args):
-        if not (args.no_sort and args.no_compact):
-            raise SeqRushError(-6, "only --no-sort --no-compact output is implemented "
-                                   "(compaction / Ygs sort are outside the hot path)")
-        text, _, _ = self.ctx.build_gfa()            # graph induction on the device
+        if not args.no_sort:
+            raise SeqRushError(-6, "only --no-sort output is implemented (the Ygs layout -- path-guided SGD, grooming, "
+                                   "topological sort -- is outside the hot path and not reproducible run to run, "
+                                   "SURVEY 0.4); compaction runs unless --no-compact")
+        text, _, _ = self.ctx.build_gfa(compact=not args.no_compact)   # graph induction on the device, compaction on the host
         with open(args.output, "w") as fh:
             fh.write(text)
 

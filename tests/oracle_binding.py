@@ -13,7 +13,7 @@ _LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
 
 
 def build_oracle(force=False):
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("uf.c", "wfa.c", "seqrush.c", "sr_oracle.h")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("uf.c", "wfa.c", "seqrush.c", "compact.c", "sr_oracle.h")]
     if (not force and os.path.exists(_LIB_PATH)
             and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
         return _LIB_PATH
@@ -132,6 +132,8 @@ def lib():
     L.sro_sparsified_pairs.argtypes = [C.POINTER(SeqRushS), C.POINTER(Sparsification), u64, i32,
                                        C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(C.c_uint32)),
                                        C.POINTER(u64)]
+    L.sro_compact_gfa.restype = vp
+    L.sro_compact_gfa.argtypes = [C.c_char_p, C.POINTER(u64), C.POINTER(u64)]
     L.sro_build_gfa.restype = vp
     L.sro_build_gfa.argtypes = [C.POINTER(SeqRushS), i32, i32, C.POINTER(u64), C.POINTER(u64)]
     L.sro_canonical_labels.argtypes = [C.POINTER(SeqRushS), C.POINTER(u64)]
@@ -180,6 +182,16 @@ def cigar_bytes_to_string(cig: bytes) -> str:
     s = C.cast(p, C.c_char_p).value.decode()
     L._libc.free(p)
     return s
+
+
+def compact_gfa(gfa_text: str):
+    """compact() + renumber of the reference (src/bidirected_ops.rs:75-490) on a --no-compact GFA -> (text, nodes, edges)"""
+    L = lib()
+    nn = C.c_uint64(); ne = C.c_uint64()
+    p = L.sro_compact_gfa(gfa_text.encode(), C.byref(nn), C.byref(ne))
+    s = C.cast(p, C.c_char_p).value.decode()
+    L._libc.free(p)
+    return s, nn.value, ne.value
 
 
 def parse_scores(s: str):
