@@ -196,6 +196,9 @@ int sr_ctx_merge_labels(sr_ctx *c, const uint64_t *dev_labels, uint32_t count);
 int sr_ctx_labels_device_u32(sr_ctx *c, uint32_t *dev_labels);
 int sr_ctx_merge_labels_u32(sr_ctx *c, const uint32_t *dev_labels, uint32_t count);
 int sr_ctx_download_labels(sr_ctx *c, uint64_t *labels_out);
+/* the merge with `count` label arrays resident on the HOST (uf_size entries each): hosts without a collective
+ * library exchange the arrays through files (seqrush_mi355x --shard R/N --labels-out / --labels-in) */
+int sr_ctx_merge_labels_host(sr_ctx *c, const uint64_t *labels, uint32_t count);
 /* Seam 3, input side (`seqrush -p file.paf`, src/seqrush.rs:510-609): replaces sr_ctx_load + sr_ctx_align.
  * Every record of the PAF file whose names are known and that carries a cg:Z: tag is replayed through
  * process_alignment's rules (src/seqrush.rs:1134-1481: bases of M/= ops are compared, runs >= min_match_len

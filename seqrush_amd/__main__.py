@@ -1,9 +1,11 @@
 """`python -m seqrush_amd` -- thin CLI with the reference's flag surface for the hot path
 (src/seqrush.rs:17-152, src/main.rs:4-7).  Everything that computes runs on the GPU."""
 import argparse
+import os
+import subprocess
 import sys
 
-from .seqrush import Args, run_seqrush
+from .seqrush import Args, run_seqrush, run_seqrush_rank
 from ._lib import SeqRushError
 
 
@@ -24,14 +26,29 @@ def main(argv=None):
     ap.add_argument("--aligner", default="allwave")
     ap.add_argument("-v", "--verbose", action="store_true")
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="GPUs of this node: the pair list is sharded, one process per GPU (torch.distributed.run, RCCL)")
     ns = ap.parse_args(argv)
+    if ns.gpus > 1 and "RANK" not in os.environ:
+        # start one process per GPU BEFORE anything here touches the GPU (never exec from a process that has)
+        port = os.environ.get("MASTER_PORT", str(29400 + os.getpid() % 2000))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ns.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", port, "-m", "seqrush_amd"] + list(argv if argv is not None else sys.argv[1:])
+        env = dict(os.environ)
+        env["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + os.pathsep + env.get("PYTHONPATH", "")
+        return subprocess.call(cmd, env=env)
     args = Args(sequences=ns.sequences, output=ns.output, min_match_length=ns.min_match_length,
                 threads=ns.threads, scores=ns.scores, orientation_scores=ns.orientation_scores,
                 max_divergence=ns.max_divergence, sparsification=ns.sparsification, paf=ns.paf,
                 output_alignments=ns.output_alignments, no_compact=ns.no_compact, no_sort=ns.no_sort,
-                aligner=ns.aligner, verbose=ns.verbose, device=ns.device)
+                aligner=ns.aligner, verbose=ns.verbose, device=ns.device, gpus=ns.gpus)
     try:
-        run_seqrush(args)
+        if ns.gpus > 1:
+            if int(os.environ.get("WORLD_SIZE", "1")) != ns.gpus:
+                raise ValueError(f"--gpus {ns.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE')}")
+            run_seqrush_rank(args)
+        else:
+            run_seqrush(args)
     except (SeqRushError, ValueError) as e:
         print(f"Error: {e}", file=sys.stderr)
         return 1

@@ -24,7 +24,7 @@ EXPORTS = [
     "sr_ctx_load_paf", "sr_unite_paf", "sr_ctx_build_gfa", "sr_ctx_load_pairs", "sr_ctx_pairs",
     "sr_ctx_num_batches", "sr_ctx_workspace_report", "sr_ctx_run", "sr_ctx_align_all", "sr_ctx_pair_results",
     "sr_ctx_labels_device_u32", "sr_ctx_merge_labels_u32", "sr_ctx_counters_ext",
-    "sr_build_gfa_opts", "sr_ctx_build_gfa_opts",
+    "sr_build_gfa_opts", "sr_ctx_build_gfa_opts", "sr_ctx_merge_labels_host",
 ]
 
 
@@ -106,6 +106,7 @@ def load():
     L.sr_ctx_labels_device.argtypes = [vp, vp]
     L.sr_ctx_merge_labels.argtypes = [vp, vp, C.c_uint32]
     L.sr_ctx_download_labels.argtypes = [vp, C.POINTER(u64)]
+    L.sr_ctx_merge_labels_host.argtypes = [vp, C.POINTER(u64), C.c_uint32]
     L.sr_ctx_kernel_ms.argtypes = [vp, i32, C.POINTER(C.c_float)]
     L.sr_ctx_align_kernel.argtypes = [vp]; L.sr_ctx_align_kernel.restype = C.c_char_p
     L.sr_ctx_load_paf.argtypes = [vp, PS, PP, C.c_char_p]

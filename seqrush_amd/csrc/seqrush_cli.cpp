@@ -42,7 +42,8 @@ static bool load_sequences(const std::string &path, std::vector<Seq> &out) {
 
 static void usage() {
     fprintf(stderr, "usage: seqrush_mi355x -s in.fa [-o output.gfa] [-k 0] [-S 0,5,8,2,24,1] [--orientation-scores 0,1,1,1]\n"
-                    "       [-d max_divergence] [-x none|auto|random:F|connectivity:P|tree:kn[,kf[,rf[,k]]]] [-p in.paf] [--output-alignments out.paf] --no-sort [--no-compact] [--device N]\n");
+                    "       [-d max_divergence] [-x none|auto|random:F|connectivity:P|tree:kn[,kf[,rf[,k]]]] [-p in.paf] [--output-alignments out.paf] --no-sort [--no-compact] [--device N]\n"
+                    "       [--shard R/N --labels-out part.bin]  |  [--labels-in part0.bin --labels-in part1.bin ...]\n");
 }
 
 int main(int argc, char **argv) {
@@ -52,6 +53,12 @@ int main(int argc, char **argv) {
     double max_div = -1.0;
     int device = 0;
     bool no_sort = false, no_compact = false;
+    // multi-GPU without a collective library in this host: every process aligns one shard (--shard R/N) and writes its
+    // canonical labels (--labels-out); a last run merges the files (--labels-in, repeatable) and writes the graph.
+    // (With RCCL at hand the exchange is one all-gather: python -m seqrush_amd --gpus N, bench.py.)
+    unsigned shard_rank = 0, shard_count = 1;
+    std::string labels_out;
+    std::vector<std::string> labels_in;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto val = [&](const char *name) -> const char * {
@@ -72,6 +79,9 @@ int main(int argc, char **argv) {
         else if (a == "--no-sort") no_sort = true;
         else if (a == "--no-compact") no_compact = true;
         else if (a == "--device") device = atoi(val("--device"));
+        else if (a == "--shard") { if (sscanf(val("--shard"), "%u/%u", &shard_rank, &shard_count) != 2 || shard_count == 0 || shard_rank >= shard_count) { fprintf(stderr, "error: --shard R/N\n"); return 2; } }
+        else if (a == "--labels-out") labels_out = val("--labels-out");
+        else if (a == "--labels-in") labels_in.push_back(val("--labels-in"));
         else if (a == "-v" || a == "--verbose") {}
         else { usage(); return 2; }
     }
@@ -94,19 +104,31 @@ int main(int argc, char **argv) {
         return 1;
     }
     p.min_match_len = (uint64_t)k; p.max_divergence = max_div; p.device = device; p.canonical_labels = 1;
+    p.shard_rank = shard_rank; p.shard_count = shard_count;
     printf("Building graph with %zu sequences (total length: %zu)\n", seqs.size(), bases.size());
     printf("Total sequence pairs: %zu (sparsification: %s)\n", seqs.size() * seqs.size(), sparsify.c_str());
     // one resident context: load (or PAF replay) -> align -> unite -> graph induction, all on the device
     sr_ctx *ctx = nullptr;
     auto die = [&]() { fprintf(stderr, "Error: %s\n", sr_last_error()); if (ctx) sr_ctx_destroy(ctx); return 1; };
     if (sr_ctx_create(device, &ctx)) return die();
-    if (!paf_in.empty()) {                                   // align_and_unite_from_paf (src/seqrush.rs:510-609)
+    if (!labels_in.empty()) {                                // merge run: no pairs of its own, the forests come from files
+        if (sr_ctx_load_pairs(ctx, &set, &p, nullptr, nullptr, 0)) return die();
+        const uint64_t ufn = sr_ctx_uf_size(ctx);
+        std::vector<uint64_t> lab(ufn);
+        for (const std::string &path : labels_in) {
+            FILE *f = fopen(path.c_str(), "rb");
+            if (!f || fread(lab.data(), 8, ufn, f) != ufn) { fprintf(stderr, "Error: cannot read %llu labels from %s\n", (unsigned long long)ufn, path.c_str()); if (f) fclose(f); sr_ctx_destroy(ctx); return 1; }
+            fclose(f);
+            if (sr_ctx_merge_labels_host(ctx, lab.data(), 1)) return die();
+        }
+    } else if (!paf_in.empty()) {                            // align_and_unite_from_paf (src/seqrush.rs:510-609)
         printf("Reading alignments from PAF file: %s\n", paf_in.c_str());
         if (sr_ctx_load_paf(ctx, &set, &p, paf_in.c_str())) return die();
     } else {
         if (sr_ctx_load(ctx, &set, &p)) return die();
     }
-    if (!paf_in.empty() || paf_out.empty()) {
+    if (!labels_in.empty()) {
+    } else if (!paf_in.empty() || paf_out.empty()) {
         if (sr_ctx_run(ctx)) return die();                   // align + unite, batch after batch (PAF input: unite only)
     } else {                                                 // --output-alignments (src/seqrush.rs:678-716)
         sr_alignments *al = nullptr;
@@ -116,6 +138,17 @@ int main(int argc, char **argv) {
         sr_alignments_free(al);
     }
     if (sr_ctx_sync(ctx)) return die();
+    if (!labels_out.empty()) {                               // shard run: the forest's canonical labels, no graph
+        const uint64_t ufn = sr_ctx_uf_size(ctx);
+        std::vector<uint64_t> lab(ufn);
+        if (sr_ctx_download_labels(ctx, lab.data())) return die();
+        FILE *f = fopen(labels_out.c_str(), "wb");
+        if (!f || fwrite(lab.data(), 8, ufn, f) != ufn) { fprintf(stderr, "Error: cannot write %s\n", labels_out.c_str()); if (f) fclose(f); sr_ctx_destroy(ctx); return 1; }
+        fclose(f);
+        printf("Labels of shard %u/%u written to %s\n", shard_rank, shard_count, labels_out.c_str());
+        sr_ctx_destroy(ctx);
+        return 0;
+    }
     char *gfa = nullptr;
     uint64_t nn = 0, ne = 0;
     if (sr_ctx_build_gfa_opts(ctx, &set, no_compact ? 0 : 1, &gfa, &nn, &ne)) return die();   // compact + renumber unless --no-compact

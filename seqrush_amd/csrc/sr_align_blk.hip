@@ -1,18 +1,28 @@
 // sr_align_blk.hip -- translation unit of the score-blocked, wave-tiled biWFA kernel (see sr_align_blk.inc)
 #include "sr_dev_common.h"
 #define SR_BLK_TU 1
-// 16 segments (32 aligners) per pass keep the static LDS of a workgroup below 16 KB: 8 workgroups per CU
 #undef SR_BFS_MAXACT
+#ifdef SR_BLK_WAVE
+// One-wave workgroups (-DSR_BLK_WAVE): a pair is aligned start to finish by ONE wave, 16 pairs per CU.  No wave ever
+// waits for another one at a workgroup barrier, in a serial control section or for the slowest tile of a pass; the
+// SIMDs interleave 4 independent pairs each.  4 segments (8 aligners) per pass keep the static LDS near 3 KB.
+#define SR_BFS_MAXACT 4
+#define K_P2 4
+#define SR_BLK_SUB wave1
+#else
+// 16 segments (32 aligners) per pass keep the static LDS of a workgroup below 20 KB
 #define SR_BFS_MAXACT 16
+#define SR_BLK_SUB wg4
+#endif
 #define BFS_MAK_SLOTS SR_BLK_MAK_SLOTS
-namespace SR_NS {
+namespace SR_NS { namespace SR_BLK_SUB {
 #include "sr_align_bfs.inc"
 #ifndef SR_BLK_MIN_WAVES
 #define SR_BLK_MIN_WAVES 4
 #endif
 #include "sr_align_blk.inc"
-}  // namespace
-using namespace SR_NS;
+} }  // namespaces
+using namespace SR_NS::SR_BLK_SUB;
 
 template <typename OT, int NT, bool TWO, bool PROF = false>
 static int launch_blk3(const SrAlignArgs *a, int nwg, size_t lds_bytes, hipStream_t st) {
@@ -24,27 +34,64 @@ static int launch_blk3(const SrAlignArgs *a, int nwg, size_t lds_bytes, hipStrea
     hipLaunchKernelGGL((sr_align_blk_kernel<OT, NT, TWO, 5, 2, 1, PROF>), dim3(nwg), dim3(NT), lds_bytes, st, *a);
     return (int)hipGetLastError();
 }
-// penalty sets this build has a blocked instance for (host side asks before choosing impl 2)
-#if SR_SYMBITS == 2
+// exact-penalty instance: mismatch 5, o1 + e1 = 10 (the reference's default -S 0,5,8,2,24,1 and the one-piece 0,5,8,2):
+// blocks of 10 levels (sr_align_blk.inc blk_tile)
+template <typename OT, int NT, bool TWO, bool PROF = false>
+static int launch_blk10(const SrAlignArgs *a, int nwg, size_t lds_bytes, hipStream_t st) {
+    if (lds_bytes > 16 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)sr_align_blk_kernel<OT, NT, TWO, 10, 2, 1, PROF, 5, 10>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL((sr_align_blk_kernel<OT, NT, TWO, 10, 2, 1, PROF, 5, 10>), dim3(nwg), dim3(NT), lds_bytes, st, *a);
+    return (int)hipGetLastError();
+}
+// penalty sets this build has a blocked instance for (host side asks before choosing impl 2): levels per block
+#if SR_SYMBITS == 2 && !defined(SR_BLK_WAVE)
 extern "C" int srk_align_blk_supports(const SrPen *pen, const SrPen *ori) {
+    if (ori->two || ori->e1 != 1 || ori->scope + 2 > BFS_MAK_SLOTS) return 0;
+    if (pen->e1 != 2 || (pen->two && pen->e2 != 1)) return 0;
+    if (pen->x == 5 && pen->o1 + pen->e1 == 10 && (!pen->two || pen->o2 + pen->e2 >= 10) &&
+        2 * pen->scope + 2 * 10 + 2 <= BFS_MAK_SLOTS) return 10;
     const int B = 5;
-    if (pen->x < B || pen->o1 + pen->e1 < B || pen->e1 != 2) return 0;
-    if (pen->two && (pen->o2 + pen->e2 < B || pen->e2 != 1)) return 0;
-    if (ori->two || ori->e1 != 1) return 0;
-    if (pen->scope + B + 1 > BFS_MAK_SLOTS || ori->scope + 2 > BFS_MAK_SLOTS) return 0;
+    if (pen->x < B || pen->o1 + pen->e1 < B) return 0;
+    if (pen->two && pen->o2 + pen->e2 < B) return 0;
+    if (pen->scope + B + 1 > BFS_MAK_SLOTS) return 0;
     return B;
 }
 #endif
+#ifdef SR_BLK_WAVE
+extern "C" int SRK_NAME(srk_align_blkw)(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, int nthreads, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const bool two = a->pen.two != 0;
+    (void)nthreads;
+    if (a->kblock == 10) {
+        if (off16) return two ? launch_blk10<int16_t, 64, true>(a, nwg, lds_bytes, st) : launch_blk10<int16_t, 64, false>(a, nwg, lds_bytes, st);
+        return two ? launch_blk10<int32_t, 64, true>(a, nwg, lds_bytes, st) : launch_blk10<int32_t, 64, false>(a, nwg, lds_bytes, st);
+    }
+    if (off16) return two ? launch_blk3<int16_t, 64, true>(a, nwg, lds_bytes, st) : launch_blk3<int16_t, 64, false>(a, nwg, lds_bytes, st);
+    return two ? launch_blk3<int32_t, 64, true>(a, nwg, lds_bytes, st) : launch_blk3<int32_t, 64, false>(a, nwg, lds_bytes, st);
+}
+#else
 extern "C" int SRK_NAME(srk_align_blk)(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, int nthreads, void *stream) {
     hipStream_t st = (hipStream_t)stream;
-    if (off16) {
-        if (nthreads == 128) return a->pen.two ? launch_blk3<int16_t, 128, true>(a, nwg, lds_bytes, st) : launch_blk3<int16_t, 128, false>(a, nwg, lds_bytes, st);
-        if (nthreads == 512) return a->pen.two ? launch_blk3<int16_t, 512, true>(a, nwg, lds_bytes, st) : launch_blk3<int16_t, 512, false>(a, nwg, lds_bytes, st);
+    const bool two = a->pen.two != 0;
+    if (a->kblock == 10) {
+        if (off16) {
+            if (nthreads == 512) return two ? launch_blk10<int16_t, 512, true>(a, nwg, lds_bytes, st) : launch_blk10<int16_t, 512, false>(a, nwg, lds_bytes, st);
 #if SR_SYMBITS == 2
-        // the instrumented instance (tick counters [6..15], SR_PROFILE_TICKS=1): default shape only
-        if (a->profile_ticks && a->pen.two) return launch_blk3<int16_t, 256, true, true>(a, nwg, lds_bytes, st);
+            // the instrumented instance (tick counters [6..15], SR_PROFILE_TICKS=1): default shape only
+            if (a->profile_ticks && two) return launch_blk10<int16_t, 256, true, true>(a, nwg, lds_bytes, st);
 #endif
-        return a->pen.two ? launch_blk3<int16_t, 256, true>(a, nwg, lds_bytes, st) : launch_blk3<int16_t, 256, false>(a, nwg, lds_bytes, st);
+            return two ? launch_blk10<int16_t, 256, true>(a, nwg, lds_bytes, st) : launch_blk10<int16_t, 256, false>(a, nwg, lds_bytes, st);
+        }
+        return two ? launch_blk10<int32_t, 256, true>(a, nwg, lds_bytes, st) : launch_blk10<int32_t, 256, false>(a, nwg, lds_bytes, st);
     }
-    return a->pen.two ? launch_blk3<int32_t, 256, true>(a, nwg, lds_bytes, st) : launch_blk3<int32_t, 256, false>(a, nwg, lds_bytes, st);
+    if (off16) {
+        if (nthreads == 128) return two ? launch_blk3<int16_t, 128, true>(a, nwg, lds_bytes, st) : launch_blk3<int16_t, 128, false>(a, nwg, lds_bytes, st);
+        if (nthreads == 512) return two ? launch_blk3<int16_t, 512, true>(a, nwg, lds_bytes, st) : launch_blk3<int16_t, 512, false>(a, nwg, lds_bytes, st);
+        return two ? launch_blk3<int16_t, 256, true>(a, nwg, lds_bytes, st) : launch_blk3<int16_t, 256, false>(a, nwg, lds_bytes, st);
+    }
+    return two ? launch_blk3<int32_t, 256, true>(a, nwg, lds_bytes, st) : launch_blk3<int32_t, 256, false>(a, nwg, lds_bytes, st);
 }
+#endif

@@ -573,7 +573,9 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
     // implementation: 1 = level-synchronous ("bfs") kernel, 0 = one-segment-at-a-time kernel
     // 2 = score-blocked wave-tiled kernel (when this build has an instance for the penalties)
     int impl = (std::max(pen.scope, ori.scope) + 1 <= 32) ? 1 : 0;
-    const int kblock = srk_align_blk_supports(&pen, &ori);
+    int kblock = srk_align_blk_supports(&pen, &ori);
+    // SR_BLK_LEVELS=5: the generic 5-level instance instead of the exact-penalty 10-level one (A/B runs, tests)
+    if (const char *e = getenv("SR_BLK_LEVELS")) { if (atoi(e) == 5 && kblock == 10) kblock = 5; }
     // impl 2 also stages the reversed target (4 regions) and has ~16 KB of static LDS
     if (impl && kblock > 0 && (long long)max_words * 16 + 40 * 1024 <= 160 * 1024) impl = 2;
     if (const char *e = getenv("SR_ALIGN_IMPL")) impl = std::min(impl, std::max(0, atoi(e)));
@@ -586,8 +588,11 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
     // few pairs (e.g. the 1/8 shard of C2): one pair per workgroup leaves CUs short of waves, so give every
     // pair 8 waves instead of 4 (measured 31 -> 23 ms for 529 pairs of 5 kb)
     if (impl == 2 && (uint64_t)np <= 2ULL * (uint64_t)cus + (uint64_t)cus / 2) c->nthreads = 512;
-    if (const char *e = getenv("SR_ALIGN_THREADS")) { int v = atoi(e); if (impl ? (v == 128 || v == 256 || v == 512) : (v == 64 || v == 128 || v == 256)) c->nthreads = v; }
-    const size_t lds_per_wg = c->lds_bytes + (impl == 2 ? 16 : impl ? 28 : 8) * 1024;
+    if (const char *e = getenv("SR_ALIGN_THREADS")) { int v = atoi(e); if (impl ? (v == 128 || v == 256 || v == 512 || (v == 64 && impl == 2 && sm.bits == 2)) : (v == 64 || v == 128 || v == 256)) c->nthreads = v; }
+    if (impl == 2 && c->nthreads == 128 && kblock == 10) kblock = 5;      // (the 10-level instance is built for 64 / 256 / 512 threads)
+    const bool wave_wg = impl == 2 && c->nthreads == 64;                  // one-wave workgroups: 16 pairs per CU
+    if (wave_wg) wg_per_cu = 16;
+    const size_t lds_per_wg = c->lds_bytes + (wave_wg ? 4 : impl == 2 ? 20 : impl ? 28 : 8) * 1024;
     wg_per_cu = (int)std::min<size_t>((size_t)wg_per_cu, std::max<size_t>(1, (160 * 1024) / lds_per_wg));
     const int ring_scope = std::max(pen.scope, ori.scope);
     const int ring_cap = (int)((2 * maxlen + 3 + 7) & ~7ULL);
@@ -600,7 +605,7 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
     const int gapmax = pen.two ? std::max(pen.o1, pen.o2) : pen.o1;
     auto gc = [&](int len) { int g = pen.o1 + pen.e1 * len; if (pen.two) g = std::min(g, pen.o2 + pen.e2 * len); return g; };
     const int smax_base = std::max(250 + gapmax, 2 * gc(100)) + 2 * gapmax + 4;
-    const int hist_levels = smax_base + 1 + 5;          // + one block of levels (impl 2 computes whole blocks)
+    const int hist_levels = smax_base + 1 + std::max(kblock, 5);   // + one block of levels (impl 2 computes whole blocks)
     int rmax = smax_base / pen.e1;
     if (pen.two) rmax = std::max(rmax, smax_base / pen.e2);
     const int hist_w = (2 * (rmax + pen.scope + 2) + 1 + 8 + 32 + 7) & ~7;   // rows hold whole 4-diagonal groups
@@ -614,7 +619,7 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
     if (lazy_id) kdepth = std::max(kdepth, 2 * pen.scope + 2 * kblock + 2);
     uint64_t bring_wg = ((uint64_t)(ring_scope + 1) + 4ULL * ring_hot + 4ULL * (ring_scope + 1) + 2ULL) * (uint64_t)brow;   // + NULL row + U row
     if (impl == 2) bring_wg = ((uint64_t)kdepth * 5 + 2ULL) * (uint64_t)brow + 1024;
-    int bbase_jobs = 16;
+    int bbase_jobs = wave_wg ? 4 : 16;
     if (const char *e = getenv("SR_BFS_BASE_JOBS")) bbase_jobs = std::max(1, std::min(16, atoi(e)));
     const uint64_t bhist_wg = ((uint64_t)hist_levels * 5 + 1) * (uint64_t)bbase_jobs * (uint64_t)hist_w + 1024;
     const uint64_t bseg_wg = 2ULL * SR_BFS_MAXSEG * SR_BFS_SEGREC * 4;          // bytes
@@ -731,7 +736,7 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
     a.ring_wg_stride = ring_wg; a.ring_dir_stride = ring_dir; a.ring_cap = ring_cap; a.ring_scope = ring_scope; a.ring_hot = ring_hot;
     a.hist_wg_stride = hist_wg; a.hist_w = hist_w; a.hist_levels = hist_levels;
     { const char *pt_ = getenv("SR_PROFILE_TICKS"); a.profile_ticks = (pt_ && atoi(pt_) != 0) ? 1 : 0; }
-    a.impl = impl; a.kdepth = kdepth; a.lazy_id = lazy_id; a.bring_wg_stride = bring_wg; a.brow = brow; a.bhist_wg_stride = bhist_wg; a.bbase_jobs = bbase_jobs;
+    a.impl = impl; a.kdepth = kdepth; a.kblock = kblock; a.lazy_id = lazy_id; a.bring_wg_stride = bring_wg; a.brow = brow; a.bhist_wg_stride = bhist_wg; a.bbase_jobs = bbase_jobs;
     a.cigar_base = c->d_cbase; a.counters = c->d_counters; a.error_flag = c->d_error;
     SrUniteArgs &u = c->ua;
     memset(&u, 0, sizeof(u));
@@ -1015,6 +1020,17 @@ extern "C" int sr_ctx_merge_labels_u32(sr_ctx *c, const uint32_t *dev_labels, ui
     HIPCHK(hipSetDevice(c->device));
     if (srk_merge32(c->d_nodes, c->uf_size, dev_labels, count, c->d_error, c->stream))
         return fail(SR_ERR_HIP, "merge kernel launch failed");
+    return SR_OK;
+}
+
+// host-resident label arrays (e.g. read back from files written by other processes / nodes): upload + replay-unite
+extern "C" int sr_ctx_merge_labels_host(sr_ctx *c, const uint64_t *labels, uint32_t count) {
+    if (!c || !c->loaded || !labels) return fail(SR_ERR_INVALID, "context not loaded");
+    HIPCHK(hipSetDevice(c->device));
+    for (uint32_t i = 0; i < count; i++) {
+        HIPCHK(hipMemcpyAsync(c->d_labels, labels + (uint64_t)i * c->uf_size, c->uf_size * 8, hipMemcpyHostToDevice, c->stream));
+        if (srk_merge(c->d_nodes, c->uf_size, c->d_labels, 1, c->d_error, c->stream)) return fail(SR_ERR_HIP, "merge kernel launch failed");
+    }
     return SR_OK;
 }
 

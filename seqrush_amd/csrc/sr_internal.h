@@ -12,7 +12,7 @@
 #define SR_BFS_SEGREC 16             // ints per segment record
 #define SR_BFS_MAXACT 32             // segments searched concurrently (2 aligners each)
 #define SR_BFS_BTCAP 1024
-#define SR_BLK_MAK_SLOTS 64           // ring depth the blocked kernel supports
+#define SR_BLK_MAK_SLOTS 80           // ring depth the blocked kernel supports (2 * scope + 2 * block + 2 = 74 for 0,5,8,2,24,1)
 
 enum { SR_C_M = 0, SR_C_I1 = 1, SR_C_I2 = 2, SR_C_D1 = 3, SR_C_D2 = 4 };
 // raw WFA2 op codes used in device CIGAR ops: (len << 4) | op
@@ -69,6 +69,7 @@ struct SrAlignArgs {
     int impl;                  // 0 = one segment at a time (sr_align_kernel), 1 = sr_align_bfs_kernel,
                                // 2 = sr_align_blk_kernel (rows: [kdepth][5 components] | NULL row | U row)
     int kdepth;                // ring depth of impl 2 (scope + levels per block + 1)
+    int kblock;                // impl 2: score levels per block (5: generic instance, 10: exact-penalty instance)
     void *bring;               // rows of brow offsets: M[(ring_scope+1)] | hot I1 I2 D1 D2 [ring_hot] each |
                                //   cold [(ring_scope+1)][4] | NULL row ; every aligner owns a sub-range of each row
     uint64_t bring_wg_stride;

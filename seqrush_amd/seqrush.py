@@ -39,6 +39,7 @@ class Args:
     device: int = 0                         # added: HIP device ordinal
     shard_rank: int = 0                     # added: multi-GPU pair shard
     shard_count: int = 1
+    gpus: int = 1                           # added: --gpus N, one process per GPU under torch.distributed.run
 
 
 @dataclasses.dataclass
@@ -473,6 +474,78 @@ def run_seqrush(args: Args):
     sr = SeqRush(sequences, device=args.device)
     sr.build_graph(args)
     print(f"Graph written to {args.output}")
+    return sr
+
+
+def run_seqrush_rank(args: Args):
+    """One rank of `--gpus N` (started by torch.distributed.run, one process per GPU): this rank's cost-balanced
+    shard of the pair list -> private forest -> ONE all-gather of canonical labels (u32 while 2N+2 < 2^32; RCCL over
+    xGMI) -> replay-unite on every rank -> rank 0 induces the graph and writes the GFA."""
+    import os
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    single_dev = os.environ.get("SR_BENCH_SINGLE_DEVICE") == "1"      # testing: all ranks on GPU 0, gloo
+    dev = 0 if single_dev else local
+    torch.cuda.set_device(dev)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if single_dev:
+        dist.init_process_group("gloo")
+    else:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+    args.device, args.shard_rank, args.shard_count = dev, rank, world
+    sequences = load_sequences(args.sequences)
+    if rank == 0:
+        print(f"Loaded {len(sequences)} sequences")
+        print(f"Building graph with {len(sequences)} sequences (total length: {sum(len(s.data) for s in sequences)})")
+    sr = SeqRush(sequences, device=dev)
+    ctx = sr.ctx
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    if args.paf is not None:
+        ctx.load_paf(sr.seqset, Params.from_args(args), args.paf)
+        ctx.run()
+    else:
+        ctx.load(sr.seqset, Params.from_args(args))
+        if rank == 0:
+            n = len(sequences)
+            print(f"Total sequence pairs: {n * n} (sparsification: {args.sparsification})")
+        if args.output_alignments:
+            al = ctx.align_all(unite=True)
+            al.write_paf(sr.seqset, f"{args.output_alignments}.rank{rank}")
+            al.close()
+        else:
+            ctx.run()
+    ctx.sync()
+    ufn = ctx.uf_size
+    u32 = ufn < (1 << 32)
+    ldt = torch.int32 if u32 else torch.int64
+    lab = torch.empty(ufn, dtype=ldt, device="cuda")
+    gathered = torch.empty(ufn * world, dtype=ldt, device="cuda")
+    (ctx.labels_device_u32 if u32 else ctx.labels_device)(lab.data_ptr())
+    torch.cuda.synchronize()
+    if single_dev:
+        parts = [torch.empty(ufn, dtype=ldt) for _ in range(world)]
+        dist.all_gather(parts, lab.cpu())
+        gathered.copy_(torch.cat(parts))
+    else:
+        dist.all_gather_into_tensor(gathered, lab)
+    (ctx.merge_labels_u32 if u32 else ctx.merge_labels)(gathered.data_ptr(), world)
+    ctx.sync()
+    dist.barrier()
+    if rank == 0:
+        if args.output_alignments:
+            with open(args.output_alignments, "wb") as out:
+                for r in range(world):
+                    part = f"{args.output_alignments}.rank{r}"
+                    with open(part, "rb") as fh:
+                        out.write(fh.read())
+                    os.remove(part)
+            print(f"Writing alignments to {args.output_alignments}")
+        sr.write_gfa(args)
+        print(f"Graph written to {args.output}")
+    dist.barrier()
+    dist.destroy_process_group()
     return sr
 
 

@@ -429,8 +429,10 @@ def test_run_seqrush_cli_end_to_end(gpu, tmp_path, capsys):
     o.align_and_unite(ob.default_params())
     assert canon_gfa(out.read_text()) == canon_gfa(o.gfa(canonical=True)[0])
     assert len(paf.read_text().strip().split("\n")) == 16
-    # default pipeline (compaction + Ygs sort) is outside the hot path: loud error, not a silent skip
+    # the Ygs sort of the default pipeline is outside the hot path: loud error, not a silent skip
     assert main(["-s", str(fa), "-o", str(out)]) == 1
+    assert main(["-s", str(fa), "-o", str(out), "--no-sort"]) == 0         # compaction runs unless --no-compact
+    assert canon_gfa(out.read_text()) == canon_gfa(ob.compact_gfa(o.gfa(canonical=True)[0])[0])
     empty = tmp_path / "e.fa"
     empty.write_bytes(b">a\nACGT\n>b\n\n")
     assert main(["-s", str(empty), "-o", str(out), "--no-sort", "--no-compact"]) == 1
@@ -440,7 +442,7 @@ KERNELS = {"0": "sr_align_kernel", "1": "sr_align_bfs_kernel", "2": "sr_align_bl
 
 
 @pytest.mark.parametrize("impl,threads", [("0", "128"), ("0", "256"), ("1", "128"), ("1", "512"),
-                                          ("2", "128"), ("2", "256"), ("2", "512")])
+                                          ("2", "64"), ("2", "128"), ("2", "256"), ("2", "512")])
 def test_all_align_kernels_and_workgroup_sizes(gpu, impl, threads, monkeypatch):
     """sr_align_kernel (one segment at a time, SR_ALIGN_IMPL=0), sr_align_bfs_kernel (level-synchronous, =1)
     and sr_align_blk_kernel (score-blocked wave tiles, default) implement the same rules: each must match
@@ -567,7 +569,16 @@ def test_cpp_cli_binary(gpu, tmp_path):
     o.align_and_unite(ob.default_params())
     assert canon_gfa(out.read_text()) == canon_gfa(o.gfa(canonical=True)[0])
     r = subprocess.run([exe, "-s", str(fa), "-o", str(out)], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 1 and "only --no-sort --no-compact" in r.stderr
+    assert r.returncode == 1 and "only --no-sort output" in r.stderr
+    # --no-sort without --no-compact: compact() + renumber (src/bidirected_gfa_writer.rs:39-51), C++ and Python hosts
+    outc, outp = tmp_path / "c.gfa", tmp_path / "cp.gfa"
+    r = subprocess.run([exe, "-s", str(fa), "-o", str(outc), "-k", "0", "--no-sort"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    want = ob.compact_gfa(o.gfa(canonical=True)[0])[0]
+    assert canon_gfa(outc.read_text()) == canon_gfa(want)
+    from seqrush_amd.__main__ import main as pymain
+    assert pymain(["-s", str(fa), "-o", str(outp), "--no-sort"]) == 0
+    assert outp.read_text() == outc.read_text()
     # --output-alignments then -p (both directions of seam 3): same graph from the replayed PAF, C++ and Python hosts
     paf, out2, out3 = tmp_path / "o.paf", tmp_path / "o2.gfa", tmp_path / "o3.gfa"
     r = subprocess.run([exe, "-s", str(fa), "-o", str(out), "--no-sort", "--no-compact", "--output-alignments", str(paf)],
@@ -885,3 +896,61 @@ def test_full_size_c5_properties(gpu):
         assert int(al.score[i]) == int(S[q, t]) and bool(al.is_reverse[i]) == bool(R[q, t])
         qs = synth.reverse_complement(recs[q][1]) if al.is_reverse[i] else recs[q][1]
         assert ob.cigar_score(al.raw_cigar_bytes(i), qs, recs[t][1], pen) == int(S[q, t])
+
+
+def test_compaction_after_device_induction(gpu):
+    """SURVEY 8(f) rank 3 end to end on the device path: graph induction kernels -> compact() + renumber
+    (sr_compact.cpp) -> GFA == the oracle's literal restatement (src/bidirected_ops.rs:75-490), RC members included;
+    the host-label entry point gives the same text"""
+    for recs in (synth.snp_family(6, 900, 0.05, 701, rc_every=3), synth.indel_family(5, 1200, 0.04, 0.02, 702),
+                 [("full", synth.to_bytes(synth.base_sequence(400, 703))), ("suffix", synth.to_bytes(synth.base_sequence(400, 703))[150:])]):
+        ss = SeqSet(recs); ctx = Context(0); ctx.load(ss, Params()); ctx.run(); ctx.sync()
+        dev, nn, ne = ctx.build_gfa(compact=True)
+        labels = ctx.download_labels(); ctx.close()
+        assert (dev, nn, ne) == build_gfa(ss, labels, compact=True)
+        o = ob.OracleSeqRush(records=recs)
+        o.align_and_unite(ob.default_params())
+        want, on, oe = ob.compact_gfa(o.gfa(canonical=True)[0])
+        assert (nn, ne) == (on, oe) and canon_gfa(dev) == canon_gfa(want)
+        assert nn < build_gfa(ss, labels)[1]
+
+
+def test_multi_gpu_cli_hosts(gpu, tmp_path):
+    """SURVEY 8(b) `--gpus N`: the Python CLI starts one process per GPU under torch.distributed.run before it touches
+    the GPU (here 2 ranks share GPU 0 over gloo: SR_BENCH_SINGLE_DEVICE); the C++ host shards with --shard R/N and
+    merges label files.  Both give the single-GPU graph; the PAF of all shards replays to the same graph."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    recs = synth.snp_family(6, 500, 0.05, 711, rc_every=3)
+    fa = tmp_path / "in.fa"
+    fa.write_bytes(b"".join(b">" + n.encode() + b"\n" + s + b"\n" for n, s in recs))
+    o = ob.OracleSeqRush(records=recs)
+    o.align_and_unite(ob.default_params())
+    want = canon_gfa(ob.compact_gfa(o.gfa(canonical=True)[0])[0])
+    env = dict(os.environ, SR_BENCH_SINGLE_DEVICE="1", PYTHONPATH=root, MASTER_PORT="29611")
+    out, paf = tmp_path / "mg.gfa", tmp_path / "mg.paf"
+    r = subprocess.run([sys.executable, "-m", "seqrush_amd", "-s", str(fa), "-o", str(out), "--no-sort", "--gpus", "2",
+                        "--output-alignments", str(paf)], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "Loaded 6 sequences" in r.stdout and f"Graph written to {out}" in r.stdout
+    assert canon_gfa(out.read_text()) == want
+    assert len(paf.read_text().strip().split("\n")) == 36
+    exe = os.path.join(root, "seqrush_amd", "seqrush_mi355x")
+    parts = []
+    for rk in range(3):
+        part = tmp_path / f"part{rk}.bin"
+        r = subprocess.run([exe, "-s", str(fa), "--shard", f"{rk}/3", "--labels-out", str(part), "--no-sort"],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and f"Labels of shard {rk}/3" in r.stdout, r.stderr
+        parts.append(str(part))
+    out2 = tmp_path / "merged.gfa"
+    cmd = [exe, "-s", str(fa), "-o", str(out2), "--no-sort"]
+    for p_ in parts:
+        cmd += ["--labels-in", p_]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert canon_gfa(out2.read_text()) == want
+    out3 = tmp_path / "frompaf.gfa"
+    r = subprocess.run([exe, "-s", str(fa), "-o", str(out3), "--no-sort", "-p", str(paf)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and canon_gfa(out3.read_text()) == want
