@@ -116,10 +116,10 @@ def build_config(name, nseq):
         return recs, "tree:3,3,0.1", "C4: 1024 x 2 kb synthetic (16 clades), -x tree:3,3,0.1", \
             "aligned pairs/sec 1024x2kb tree:3,3,0.1"
     if name == "C5":
-        recs = synth.config_c5()
-        return recs, "none", ("C5: 256 x 50 kb synthetic (2% substitutions, 0.1% indels, in-place inversions in 25%, 10% "
-                              "reverse-complemented), all-vs-all incl. self = 65536 ordered pairs"), \
-            "aligned pairs/sec all-vs-all 256x50kb"
+        recs = synth.config_c5(nseq)
+        return recs, "none", (f"C5: {nseq} x 50 kb synthetic (2% substitutions, 0.1% indels, in-place inversions in 25%, 10% "
+                              f"reverse-complemented), all-vs-all incl. self = {nseq * nseq} ordered pairs"), \
+            f"aligned pairs/sec all-vs-all {nseq}x50kb"
     raise SystemExit(f"unknown --config {name}")
 
 
@@ -129,9 +129,11 @@ def main():
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", default="C2", choices=["C2", "C3", "C4", "C5"])
-    ap.add_argument("--nseq", type=int, default=64, help="C2 only: number of 5 kb sequences")
+    ap.add_argument("--nseq", type=int, default=None, help="C2 / C5: number of sequences (default 64 / 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.nseq is None:
+        args.nseq = 256 if args.config == "C5" else 64
     if args.steps is None:
         args.steps = 1 if args.config == "C5" else 5
     if args.warmup is None:
@@ -252,7 +254,7 @@ def main():
         achieved = row_bytes / (a_ms * 1e-3) / 1e9 if a_ms > 0 else 0.0
         pmc = {}
         ppath = os.path.join(ROOT, "profiles", "r02_counters.json")
-        if world == 1 and args.config == "C2" and args.nseq == 64 and os.path.exists(ppath):
+        if world == 1 and args.config == "C2" and args.nseq == 64 and os.path.exists(ppath) and not os.environ.get("SR_BLK_LEVELS"):
             try:
                 pmc = json.load(open(ppath))
             except Exception:

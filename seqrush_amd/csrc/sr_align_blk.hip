@@ -64,7 +64,8 @@ extern "C" int srk_align_blk_supports(const SrPen *pen, const SrPen *ori) {
 extern "C" int SRK_NAME(srk_align_blkw)(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, int nthreads, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     const bool two = a->pen.two != 0;
-    (void)nthreads;
+    if (a->kblock == 10 && nthreads == 128 && off16)          // two-wave workgroups, 8 per CU (same lean LDS state)
+        return two ? launch_blk10<int16_t, 128, true>(a, nwg, lds_bytes, st) : launch_blk10<int16_t, 128, false>(a, nwg, lds_bytes, st);
     if (a->kblock == 10) {
         if (off16) return two ? launch_blk10<int16_t, 64, true>(a, nwg, lds_bytes, st) : launch_blk10<int16_t, 64, false>(a, nwg, lds_bytes, st);
         return two ? launch_blk10<int32_t, 64, true>(a, nwg, lds_bytes, st) : launch_blk10<int32_t, 64, false>(a, nwg, lds_bytes, st);

@@ -589,9 +589,9 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
     // pair 8 waves instead of 4 (measured 31 -> 23 ms for 529 pairs of 5 kb)
     if (impl == 2 && (uint64_t)np <= 2ULL * (uint64_t)cus + (uint64_t)cus / 2) c->nthreads = 512;
     if (const char *e = getenv("SR_ALIGN_THREADS")) { int v = atoi(e); if (impl ? (v == 128 || v == 256 || v == 512 || (v == 64 && impl == 2 && sm.bits == 2)) : (v == 64 || v == 128 || v == 256)) c->nthreads = v; }
-    if (impl == 2 && c->nthreads == 128 && kblock == 10) kblock = 5;      // (the 10-level instance is built for 64 / 256 / 512 threads)
-    const bool wave_wg = impl == 2 && c->nthreads == 64;                  // one-wave workgroups: 16 pairs per CU
-    if (wave_wg) wg_per_cu = 16;
+    if (impl == 2 && c->nthreads == 128 && kblock == 10 && !(sm.bits == 2 && c->off16)) kblock = 5;   // (no 128-thread 10-level instance there)
+    const bool wave_wg = impl == 2 && (c->nthreads == 64 || (c->nthreads == 128 && kblock == 10));   // lean builds: 16 / 8 pairs per CU
+    if (wave_wg) wg_per_cu = c->nthreads == 64 ? 16 : 8;
     const size_t lds_per_wg = c->lds_bytes + (wave_wg ? 4 : impl == 2 ? 20 : impl ? 28 : 8) * 1024;
     wg_per_cu = (int)std::min<size_t>((size_t)wg_per_cu, std::max<size_t>(1, (160 * 1024) / lds_per_wg));
     const int ring_scope = std::max(pen.scope, ori.scope);
@@ -619,7 +619,7 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
     if (lazy_id) kdepth = std::max(kdepth, 2 * pen.scope + 2 * kblock + 2);
     uint64_t bring_wg = ((uint64_t)(ring_scope + 1) + 4ULL * ring_hot + 4ULL * (ring_scope + 1) + 2ULL) * (uint64_t)brow;   // + NULL row + U row
     if (impl == 2) bring_wg = ((uint64_t)kdepth * 5 + 2ULL) * (uint64_t)brow + 1024;
-    int bbase_jobs = wave_wg ? 4 : 16;
+    int bbase_jobs = wave_wg ? (c->nthreads == 64 ? 4 : 8) : 16;
     if (const char *e = getenv("SR_BFS_BASE_JOBS")) bbase_jobs = std::max(1, std::min(16, atoi(e)));
     const uint64_t bhist_wg = ((uint64_t)hist_levels * 5 + 1) * (uint64_t)bbase_jobs * (uint64_t)hist_w + 1024;
     const uint64_t bseg_wg = 2ULL * SR_BFS_MAXSEG * SR_BFS_SEGREC * 4;          // bytes
@@ -696,8 +696,12 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
         if (bcl_wg) { if ((r = dev_alloc(c, &d, (uint64_t)nwg * bcl_wg * 4))) return r; a.bcl = (uint32_t *)d; a.bcl_wg_stride = bcl_wg; }
         if (impl == 2) { if ((r = dev_alloc(c, &d, (uint64_t)nwg * 32 * SR_BLK_MAK_SLOTS * 4))) return r; a.bmak = (int *)d; }
         // orientation as its own kernel, one pair per wave (sr_orient.hip); SR_PREORIENT=0 keeps it in the alignment kernel
+        // Worth it when there are enough pairs to fill the chip with one wave each and the three sequence copies of a
+        // wave leave >= 8 waves per CU (measured: C2 / C4 faster; C3 -- 144 pairs -- 1.6x and C5 -- 50 kb, 4 waves per
+        // CU by LDS -- 9 % slower than orientation inside the alignment kernel's workgroup).  SR_PREORIENT=1 / 0 forces.
         const char *po = getenv("SR_PREORIENT");
-        if (impl == 2 && !(po && atoi(po) == 0) && (size_t)max_words * 12 <= 60 * 1024) {
+        const bool pre_auto = (uint64_t)np >= 4ULL * (uint64_t)cus && (size_t)max_words * 12 <= 20 * 1024;
+        if (impl == 2 && (po ? atoi(po) != 0 : pre_auto) && (size_t)max_words * 12 <= 60 * 1024) {
             const int orow = (int)((2 * ((2 * maxlen + 32) & ~3ULL) + 512 + 7) & ~7ULL);
             const uint64_t oring_wg = ((uint64_t)(ori.scope + 1) * 3 + 1) * (uint64_t)orow + 256;
             int onwg = (int)std::min<uint64_t>(max_batch_pairs, (uint64_t)cus * 16);

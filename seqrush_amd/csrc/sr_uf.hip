@@ -234,7 +234,7 @@ extern "C" int srk_orient_s8(const SrAlignArgs *a, int nwg, size_t lds_bytes, in
 
 extern "C" int srk_align_blkw_s2(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, int nthreads, void *stream);
 extern "C" int srk_align(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, int nthreads, void *stream) {
-    if (a->impl == 2 && nthreads == 64) {                        // one-wave workgroups (built for 2-bit buffers)
+    if (a->impl == 2 && (nthreads == 64 || (nthreads == 128 && a->kblock == 10 && off16))) {   // one- / two-wave workgroups (2-bit buffers)
         if (a->symbits != 2) return (int)hipErrorInvalidValue;
         return srk_align_blkw_s2(a, nwg, lds_bytes, off16, nthreads, stream);
     }

@@ -766,6 +766,13 @@ def test_config_c4_scaled_parity(gpu):
 
 
 # --------------------------------------------------------------------------- round 2: BASELINE configs at size
+def _ms(ctx, which):
+    try:
+        return ctx.kernel_ms(which)
+    except sa.SeqRushError:
+        return None                      # (orientation ran inside the alignment kernel: no kernel of its own)
+
+
 def _report(name, ctx, t_ms, extra=None):
     """sizing + timing of a full-size run, kept under gpurun_out/ for DESIGN.md"""
     import json
@@ -840,7 +847,7 @@ def test_full_size_c4_properties(gpu):
     labels = ctx.download_labels()
     gfa, nn, ne = ctx.build_gfa()
     _report("C4", ctx, dt, {"pairs": len(pairs), "load_ms_incl_sketches": t_load, "nodes": nn, "edges": ne,
-                            "align_ms": ctx.kernel_ms(0), "orient_ms": ctx.kernel_ms(4), "unite_ms": ctx.kernel_ms(1)})
+                            "align_ms": ctx.kernel_ms(0), "orient_ms": _ms(ctx, 4), "unite_ms": ctx.kernel_ms(1)})
     ctx.close()
     d = {p: int(s) for p, s in zip(pairs, sc)}
     assert all(s >= 0 for s in d.values()) and all(d[(q, q)] == 0 for q in range(1024))
@@ -878,7 +885,7 @@ def test_full_size_c5_properties(gpu):
     sc, rv, co = ctx.pair_results()
     labels = ctx.download_labels()
     cnt = ctx.counters()
-    _report("C5", ctx, dt, {"pairs": n * n, "align_ms": ctx.kernel_ms(0), "orient_ms": ctx.kernel_ms(4),
+    _report("C5", ctx, dt, {"pairs": n * n, "align_ms": ctx.kernel_ms(0), "orient_ms": _ms(ctx, 4),
                             "unite_ms": ctx.kernel_ms(1), "wf_cells": cnt["wf_cells"], "max_score": int(sc.max()),
                             "mean_score": float(sc.mean())})
     ctx.close()
@@ -912,7 +919,9 @@ def test_compaction_after_device_induction(gpu):
         o.align_and_unite(ob.default_params())
         want, on, oe = ob.compact_gfa(o.gfa(canonical=True)[0])
         assert (nn, ne) == (on, oe) and canon_gfa(dev) == canon_gfa(want)
-        assert nn < build_gfa(ss, labels)[1]
+        # (the suffix case merges nothing: a path enters the only chain in the middle and merge_component_v2 refuses it)
+        plain_nodes = build_gfa(ss, labels)[1]
+        assert nn <= plain_nodes and (nn < plain_nodes or recs[1][0] == "suffix")
 
 
 def test_multi_gpu_cli_hosts(gpu, tmp_path):
