@@ -51,6 +51,28 @@ __global__ void __launch_bounds__(256) calib_wr8_scatter(u2 *buf, uint64_t nchun
         if (NT) __builtin_nontemporal_store(v, p + c * 64 + lane); else p[c * 64 + lane] = v;
     }
 }
+// the alignment kernel's mix: per iteration R scattered chunk loads and W scattered chunk stores (8 B per lane);
+// the loads of an iteration are issued together, their sum is consumed, then the stores -- like a tile
+template <int R, int W>
+__global__ void __launch_bounds__(256) calib_mix8_scatter(u2 *buf, uint64_t nchunks, int iters, uint64_t *sink) {
+    const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    GP<u2> p = (GP<u2>)buf;
+    u2 acc = {0u, 0u};
+    for (int i = 0; i < iters; i++) {
+        u2 v[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) v[r] = p[(mix(wave * 1000003ULL + (uint64_t)i * 16 + r) % nchunks) * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < R; r++) { acc.x ^= v[r].x; acc.y += v[r].y; }
+#pragma unroll
+        for (int w = 0; w < W; w++) {
+            const u2 o = {acc.x + (uint32_t)w, acc.y};
+            p[(mix(wave * 1000003ULL + (uint64_t)i * 16 + 8 + w) % nchunks) * 64 + lane] = o;
+        }
+    }
+    if (acc.x == 0x12345678u && acc.y == 0x9abcdef0u) sink[0] = acc.x;
+}
 // streaming 16 B per lane (the guide's calibrated shape: FETCH_SIZE reads 1/2, WRITE_SIZE exact)
 __global__ void __launch_bounds__(256) calib_rd16_stream(const u4 *buf, uint64_t n16, uint64_t *sink) {
     GP<const u4> p = (GP<const u4>)buf;
@@ -123,6 +145,10 @@ int main(int argc, char **argv) {
         {"calib_rd8_scatter<true>", scat_bytes, [](hipStream_t s) { hipLaunchKernelGGL(calib_rd8_scatter<true>, dim3(g_wgs), dim3(256), 0, s, (const u2 *)g_buf, g_nchunks, g_iters, g_sink); }},
         {"calib_wr8_scatter<false>", scat_bytes, [](hipStream_t s) { hipLaunchKernelGGL(calib_wr8_scatter<false>, dim3(g_wgs), dim3(256), 0, s, (u2 *)g_buf, g_nchunks, g_iters); }},
         {"calib_wr8_scatter<true>", scat_bytes, [](hipStream_t s) { hipLaunchKernelGGL(calib_wr8_scatter<true>, dim3(g_wgs), dim3(256), 0, s, (u2 *)g_buf, g_nchunks, g_iters); }},
+        {"calib_mix8_scatter<3, 2>", (uint64_t)g_wgs * 4 * (g_iters / 4) * 512 * 5, [](hipStream_t s) { hipLaunchKernelGGL((calib_mix8_scatter<3, 2>), dim3(g_wgs), dim3(256), 0, s, (u2 *)g_buf, g_nchunks, g_iters / 4, g_sink); }},
+        {"calib_mix8_scatter<6, 4>", (uint64_t)g_wgs * 4 * (g_iters / 8) * 512 * 10, [](hipStream_t s) { hipLaunchKernelGGL((calib_mix8_scatter<6, 4>), dim3(g_wgs), dim3(256), 0, s, (u2 *)g_buf, g_nchunks, g_iters / 8, g_sink); }},
+        {"calib_mix8_scatter<8, 1>", (uint64_t)g_wgs * 4 * (g_iters / 8) * 512 * 9, [](hipStream_t s) { hipLaunchKernelGGL((calib_mix8_scatter<8, 1>), dim3(g_wgs), dim3(256), 0, s, (u2 *)g_buf, g_nchunks, g_iters / 8, g_sink); }},
+        {"calib_mix8_scatter<1, 4>", (uint64_t)g_wgs * 4 * (g_iters / 4) * 512 * 5, [](hipStream_t s) { hipLaunchKernelGGL((calib_mix8_scatter<1, 4>), dim3(g_wgs), dim3(256), 0, s, (u2 *)g_buf, g_nchunks, g_iters / 4, g_sink); }},
         {"calib_rd16_stream", bytes, [](hipStream_t s) { hipLaunchKernelGGL(calib_rd16_stream, dim3(256 * 16), dim3(256), 0, s, (const u4 *)g_buf, g_bytes / 16, g_sink); }},
         {"calib_wr16_stream", bytes, [](hipStream_t s) { hipLaunchKernelGGL(calib_wr16_stream, dim3(256 * 16), dim3(256), 0, s, (u4 *)g_buf, g_bytes / 16); }},
         {"calib_rd8_stream", bytes, [](hipStream_t s) { hipLaunchKernelGGL(calib_rd8_stream, dim3(256 * 16), dim3(256), 0, s, (const u2 *)g_buf, g_bytes / 8, g_sink); }},
