@@ -577,7 +577,9 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
     // SR_BLK_LEVELS=5: the generic 5-level instance instead of the exact-penalty 10-level one (A/B runs, tests)
     if (const char *e = getenv("SR_BLK_LEVELS")) { if (atoi(e) == 5 && kblock == 10) kblock = 5; }
     // impl 2 also stages the reversed target (4 regions) and has ~16 KB of static LDS
-    if (impl && kblock > 0 && (long long)max_words * 16 + 40 * 1024 <= 160 * 1024) impl = 2;
+    // (the blocked kernel has its own ring depth limit, checked by srk_align_blk_supports: it does not inherit the
+    // level-synchronous kernel's 32-slot limit)
+    if (kblock > 0 && (long long)max_words * 16 + 40 * 1024 <= 160 * 1024) impl = 2;
     if (const char *e = getenv("SR_ALIGN_IMPL")) impl = std::min(impl, std::max(0, atoi(e)));
     if (impl == 0 && sm.bits != 2)
         return fail(SR_ERR_UNSUPPORTED, "penalties with scope > 31 run on sr_align_kernel, which is built for upper-case ACGT input only");

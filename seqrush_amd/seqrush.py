@@ -366,7 +366,7 @@ class Context:
     def counters(self):
         out = (C.c_uint64 * 32)()
         check(self.L.sr_ctx_counters_ext(self._h, out))
-        return dict(row_bytes_loaded=int(out[16]), row_bytes_stored=int(out[17]),
+        return dict(row_bytes_loaded=int(out[16]), row_bytes_stored=int(out[17]), tk_recompute=int(out[18]),
                     wf_cells=int(out[0]), wf_steps=int(out[1]), base_segments=int(out[2]),
                     breakpoint_searches=int(out[3]), united_bases=int(out[4]), match_runs=int(out[5]),
                     ticks_orientation=int(out[6]), ticks_breakpoint=int(out[7]), ticks_base=int(out[8]),

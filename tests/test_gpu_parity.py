@@ -654,6 +654,8 @@ def test_raw_byte_alphabet_on_fallback_kernel_and_in_kernel_orientation(gpu, mon
     recs = ALPHA_CASES["mixed-indel-rc"]()
     _, _, cnt = check_parity(recs, scores="0,4,6,2,24,1")          # no blocked instance: sr_align_bfs_kernel, 4-bit build
     assert cnt["align_kernel"] == "sr_align_bfs_kernel"
+    _, _, cnt = check_parity(recs, scores="0,6,9,2,30,1")          # scope 32: blocked kernel (own ring depth limit), 4-bit build
+    assert cnt["align_kernel"] == "sr_align_blk_kernel"
     monkeypatch.setenv("SR_PREORIENT", "0")                        # orientation inside the blocked kernel: the copy reload path
     check_parity(recs)
     check_parity(ALPHA_CASES["soft-masked-rc"]())
