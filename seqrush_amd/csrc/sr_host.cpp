@@ -583,7 +583,7 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
     if (const char *e = getenv("SR_ALIGN_IMPL")) impl = std::min(impl, std::max(0, atoi(e)));
     if (impl == 0 && sm.bits != 2)
         return fail(SR_ERR_UNSUPPORTED, "penalties with scope > 31 run on sr_align_kernel, which is built for upper-case ACGT input only");
-    if (impl == 2) c->lds_bytes = (size_t)max_words * 4 * 4;
+    if (impl == 2) c->lds_bytes = (size_t)max_words * 4 * 4 + 16;      // (+ read slack of a two-window extension step)
     int wg_per_cu = impl ? 4 : 8;
     if (const char *e = getenv("SR_WG_PER_CU")) wg_per_cu = std::max(1, atoi(e));
     c->nthreads = impl ? 256 : 128;
