@@ -8,9 +8,12 @@ from seqrush_amd import synth
 from seqrush_amd.seqrush import SeqSet, Params, Context
 recs = synth.config_c2(64); ss = SeqSet(recs)
 out = []
+ENVS = [{}, {"SR_PREORIENT": "1"}, {"SR_PREORIENT": "0"}, {"SR_ALIGN_THREADS": "256"}, {"SR_ALIGN_THREADS": "512"},
+        {"SR_ALIGN_THREADS": "512", "SR_PREORIENT": "1"}, {"SR_ALIGN_THREADS": "256", "SR_PREORIENT": "1"}]
+if len(sys.argv) > 1:                      # extra variants: "K=V,K=V;K=V"
+    ENVS = [{}] + [dict(kv.split("=") for kv in grp.split(",")) for grp in sys.argv[1].split(";")]
 for world in (8, 4, 2):
-    for env in ({}, {"SR_PREORIENT": "1"}, {"SR_PREORIENT": "0"}, {"SR_ALIGN_THREADS": "256"}, {"SR_ALIGN_THREADS": "512"},
-                {"SR_ALIGN_THREADS": "512", "SR_PREORIENT": "1"}, {"SR_ALIGN_THREADS": "256", "SR_PREORIENT": "1"}):
+    for env in ENVS:
         old = {k: os.environ.get(k) for k in env}; os.environ.update(env)
         p = Params(); p.c.shard_rank, p.c.shard_count = 0, world
         ctx = Context(0); ctx.load(ss, p)
