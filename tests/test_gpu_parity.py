@@ -122,6 +122,11 @@ def test_long_homopolymer_11068_vs_11065(gpu):
     ("rc-indel", [(n, s if i % 2 else synth.reverse_complement(s)) for i, (n, s) in enumerate(synth.indel_family(4, 400, 0.03, 0.03, 48))], {}),
     ("affine-1p", synth.indel_family(4, 800, 0.04, 0.02, 49), {"scores": "0,5,8,2"}),
     ("other-2p", synth.indel_family(4, 600, 0.05, 0.03, 50), {"scores": "0,4,6,2,12,1"}),
+    # 10-level exact instance (x = 5, o1 + e1 = 10) with other second pieces: o2 + e2 = 10 (the block depth itself), 13, 31
+    ("blk10-o2e2-10", synth.indel_family(4, 1500, 0.05, 0.03, 5010), {"scores": "0,5,8,2,9,1"}),
+    ("blk10-o2e2-13", synth.indel_family(4, 1500, 0.05, 0.03, 5013), {"scores": "0,5,8,2,12,1"}),
+    ("blk10-o2e2-31", synth.indel_family(3, 2500, 0.06, 0.03, 5031), {"scores": "0,5,8,2,30,1"}),
+    ("blk5-o2e2-9", synth.indel_family(4, 1500, 0.05, 0.03, 5009), {"scores": "0,5,8,2,8,1"}),
     ("open0", synth.indel_family(3, 400, 0.05, 0.03, 51), {"scores": "0,3,0,1"}),
     ("k8", synth.snp_family(4, 800, 0.06, 52), {"min_match_len": 8}),
     ("k64", synth.snp_family(4, 800, 0.03, 53), {"min_match_len": 64}),
