@@ -621,6 +621,8 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
     if (lazy_id) kdepth = std::max(kdepth, 2 * pen.scope + 2 * kblock + 2);
     uint64_t bring_wg = ((uint64_t)(ring_scope + 1) + 4ULL * ring_hot + 4ULL * (ring_scope + 1) + 2ULL) * (uint64_t)brow;   // + NULL row + U row
     if (impl == 2) bring_wg = ((uint64_t)kdepth * 5 + 2ULL) * (uint64_t)brow + 1024;
+    // (the blocked kernel addresses a workgroup's rows as base + 32-bit byte offset)
+    if (impl == 2 && bring_wg * osz >= (1ULL << 32)) return fail(SR_ERR_UNSUPPORTED, "sequences too long for the device row workspace (4 GB per workgroup)");
     int bbase_jobs = wave_wg ? (c->nthreads == 64 ? 4 : 8) : 16;
     if (const char *e = getenv("SR_BFS_BASE_JOBS")) bbase_jobs = std::max(1, std::min(16, atoi(e)));
     const uint64_t bhist_wg = ((uint64_t)hist_levels * 5 + 1) * (uint64_t)bbase_jobs * (uint64_t)hist_w + 1024;
@@ -655,6 +657,7 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
     const uint64_t left = avail - arena_ops * 4;
     uint64_t budget = (uint64_t)(left * 0.7);
     int nwg = cus * wg_per_cu;
+    if (const char *e = getenv("SR_NWG")) nwg = std::max(1, std::min(nwg, atoi(e)));   // (tests: several pairs per workgroup on a small input)
     if ((uint64_t)nwg > max_batch_pairs) nwg = (int)max_batch_pairs;
     if (nwg < 1) nwg = 1;
     while (nwg > 1 && (uint64_t)nwg * per_wg_bytes > budget) nwg--;
@@ -693,6 +696,14 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
     if (impl) {
         if ((r = dev_alloc(c, &d, (uint64_t)nwg * bring_wg * osz))) return r; a.bring = d;
         if ((r = dev_alloc(c, &d, (uint64_t)nwg * bhist_wg * osz))) return r; a.bhist = d;
+        // (tests: the kernels must not depend on what the row workspaces held before -- poison them with plausible offsets)
+        if (const char *e = getenv("SR_POISON_ROWS")) {
+            const int v = atoi(e);
+            if (osz == 2) { HIPCHK(hipMemsetD16Async((hipDeviceptr_t)a.bring, (unsigned short)v, (size_t)nwg * bring_wg, c->stream));
+                            HIPCHK(hipMemsetD16Async((hipDeviceptr_t)a.bhist, (unsigned short)v, (size_t)nwg * bhist_wg, c->stream)); }
+            else { HIPCHK(hipMemsetD32Async((hipDeviceptr_t)a.bring, v, (size_t)nwg * bring_wg, c->stream));
+                   HIPCHK(hipMemsetD32Async((hipDeviceptr_t)a.bhist, v, (size_t)nwg * bhist_wg, c->stream)); }
+        }
         if ((r = dev_alloc(c, &d, (uint64_t)nwg * bseg_wg))) return r; a.bseg = (int *)d;
         if ((r = dev_alloc(c, &d, (uint64_t)nwg * bbt_wg))) return r; a.bbt = (uint32_t *)d;
         if (bcl_wg) { if ((r = dev_alloc(c, &d, (uint64_t)nwg * bcl_wg * 4))) return r; a.bcl = (uint32_t *)d; a.bcl_wg_stride = bcl_wg; }

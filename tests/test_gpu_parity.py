@@ -147,6 +147,25 @@ def test_c2_subset_parity_8x5kb(gpu):
     assert cnt["breakpoint_searches"] >= 56 * 15
 
 
+@pytest.mark.parametrize("name,recs,kw,env", [
+    # (SR_NWG: at most that many workgroups, so every workgroup aligns several pairs one after the other and starts each
+    # from whatever registers, LDS tables and ring rows the previous pair left behind)
+    ("exact10-int16-1wg", synth.config_c2(4), {}, {"SR_NWG": "1"}),
+    ("exact10-int16-3wg-256t", synth.config_c2(6), {}, {"SR_NWG": "3", "SR_ALIGN_THREADS": "256"}),
+    ("exact10-one-piece", synth.indel_family(4, 2500, 0.05, 0.02, 9101), {"scores": "0,5,8,2"}, {"SR_NWG": "2", "SR_ALIGN_THREADS": "256"}),
+    ("generic5-int16", synth.config_c2(4), {}, {"SR_NWG": "1", "SR_BLK_LEVELS": "5", "SR_ALIGN_THREADS": "256"}),
+    ("generic5-other-penalties", synth.indel_family(4, 2500, 0.05, 0.02, 9102), {"scores": "0,6,9,2,30,1"}, {"SR_NWG": "2"}),
+    ("exact10-int32", synth.snp_family(3, 33000, 0.01, 9103), {}, {"SR_NWG": "1"}),
+    ("level-kernel", synth.indel_family(4, 1200, 0.05, 0.02, 9104), {"scores": "0,3,4,1"}, {"SR_NWG": "1"}),
+    ("in-kernel-orientation", synth.snp_family(4, 3000, 0.04, 9105, rc_every=2), {}, {"SR_NWG": "2", "SR_PREORIENT": "0"}),
+    ("self-pairs-in-between", [("a", synth.to_bytes(synth.base_sequence(4000, 9106)))] + synth.snp_family(2, 4000, 0.05, 9107), {}, {"SR_NWG": "1"}),
+])
+def test_several_pairs_per_workgroup(gpu, monkeypatch, name, recs, kw, env):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    check_parity(recs, **kw)
+
+
 def test_50kb_pair_int32_offsets(gpu):
     """sequences > 32 kb take the 32-bit offset kernel instantiation (LDS staging of 50 kb sequences)"""
     recs = synth.snp_family(2, 40000, 0.01, 61)
