@@ -620,7 +620,8 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
     const int lazy_id = (impl == 2 && !(lz && atoi(lz) == 0) && 2 * pen.scope + 2 * kblock + 2 <= SR_BLK_MAK_SLOTS) ? 1 : 0;
     if (lazy_id) kdepth = std::max(kdepth, 2 * pen.scope + 2 * kblock + 2);
     uint64_t bring_wg = ((uint64_t)(ring_scope + 1) + 4ULL * ring_hot + 4ULL * (ring_scope + 1) + 2ULL) * (uint64_t)brow;   // + NULL row + U row
-    if (impl == 2) bring_wg = ((uint64_t)kdepth * 5 + 2ULL) * (uint64_t)brow + 1024;
+    // impl 2: chunk-major ring (sr_align_blk.inc KRows): 256-cell pieces of all 5 * depth + 2 rows together, + 2 pieces of read slack
+    if (impl == 2) bring_wg = ((uint64_t)brow / 256 + 2ULL) * ((uint64_t)kdepth * 5 + 2ULL) * 256ULL + 1024;
     // (the blocked kernel addresses a workgroup's rows as base + 32-bit byte offset)
     if (impl == 2 && bring_wg * osz >= (1ULL << 32)) return fail(SR_ERR_UNSUPPORTED, "sequences too long for the device row workspace (4 GB per workgroup)");
     int bbase_jobs = wave_wg ? (c->nthreads == 64 ? 4 : 8) : 16;
