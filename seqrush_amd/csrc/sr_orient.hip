@@ -11,6 +11,7 @@
 // ranges are scalar arithmetic, and 16 pairs per CU keep the SIMDs busy.  Tile code = sr_align_blk.inc's
 // blk_tile for one level (4 diagonals per lane, DPP neighbours, 2 halo lanes).
 #include "sr_dev_common.h"
+#include <cstdlib>
 namespace SR_NS {
 
 __device__ __forceinline__ int o_lane_left(int x) { return __builtin_amdgcn_update_dpp(NULLV, x, 0x138, 0xf, 0xf, false); }
@@ -152,10 +153,189 @@ __global__ void __launch_bounds__(64, 4) sr_orient_kernel(SrAlignArgs a) {
     }
 }
 
+// ---- blocked instance for the default orientation penalties (mismatch 1, gap-open 1, gap-extend 1, one piece) -----
+// With x = 1, o + e = 2, e = 1 every cell of level s depends on levels s-1 and s-2 at diagonals k-1 .. k+1 only: a
+// wave tile keeps M[s-1], M[s-2], I[s-1], D[s-1] of its 4 diagonals per lane in registers and walks OB levels without
+// touching memory -- neighbours by DPP, halo of one diagonal per level and side (2 lanes for OB = 8).  Rows are read
+// and written once per OB levels (4 + 4 per tile) instead of 4 + 3 per level, and the store -> load round trip between
+// consecutive levels, which is what the level-by-level kernel spends its time on, is paid once per block.
+// Two row sets (block parity) of {M last, M last-1, I last, D last}; a block's window = the last level's range + OB + 2.
+#define OB 8
+template <typename OT>
+__global__ void __launch_bounds__(64, 4) sr_orient_blk_kernel(SrAlignArgs a) {
+    const int lane = threadIdx.x;
+    const SrPen pen = a.ori;
+    const unsigned w = (unsigned)a.orow;
+    GP<OT> ring = (GP<OT>)(OT *)a.oring + (size_t)blockIdx.x * a.oring_wg_stride;
+    GP<OT> nul = ring + (size_t)8 * w;
+    for (unsigned i = lane; i < w; i += 64) nul[i] = (OT)NULLV;
+    unsigned long long cells = 0, steps = 0;
+    int err = 0;
+    for (;;) {
+        int pair = 0;
+        if (lane == 0) pair = (int)atomicAdd(a.oqueue, 1u);
+        pair = RFL(pair);
+        if (pair >= (int)a.npairs) break;
+        if (a.order) pair = (int)a.order[pair];
+        const uint32_t q = a.pair_q[pair], t = a.pair_t[pair];
+        const int plen = (int)a.seqlen[q], tlen = (int)a.seqlen[t];
+        const int pw = SR_SEQ_WORDS(plen), tw = SR_SEQ_WORDS(tlen);
+        __syncthreads();
+        load_seq_lds<64>(lds_seq, (GP<const uint32_t>)a.seqwords + a.word_off_fwd[q] - 1, pw);
+        load_seq_lds<64>(lds_seq + a.max_words, (GP<const uint32_t>)a.seqwords + a.word_off_rc[q] - 1, pw);
+        load_seq_lds<64>(lds_seq + 2 * (size_t)a.max_words, (GP<const uint32_t>)a.seqwords + a.word_off_fwd[t] - 1, tw);
+        __syncthreads();
+        const LP T = (LP)(lds_seq + 2 * (size_t)a.max_words + 1);
+        const int shift = plen + 24, width = (plen + tlen + 64) & ~3, kend = tlen - plen;
+        int fwd = -1, rev = INT_MAX, is_rev = 0;
+        const long long smax = (long long)pen.o1 * 2 + (long long)pen.e1 * (plen + tlen) + 64;
+        for (int s0 = 0;; s0 += OB) {
+            const int par = (s0 / OB) & 1;
+            // rows of the previous block (NULL rows before the first one) and of this one
+            GP<OT> pM1 = s0 ? ring + (size_t)((1 - par) * 4 + 0) * w : nul, pM2 = s0 ? ring + (size_t)((1 - par) * 4 + 1) * w : nul;
+            GP<OT> pI = s0 ? ring + (size_t)((1 - par) * 4 + 2) * w : nul, pD = s0 ? ring + (size_t)((1 - par) * 4 + 3) * w : nul;
+            GP<OT> oM1 = ring + (size_t)(par * 4 + 0) * w, oM2 = ring + (size_t)(par * 4 + 1) * w;
+            GP<OT> oI = ring + (size_t)(par * 4 + 2) * w, oD = ring + (size_t)(par * 4 + 3) * w;
+            const int Rl = reach(pen, s0 + OB - 1, SR_C_M);
+            const int wlo = max(-plen - 1, -Rl - OB - 2), whi = min(tlen + 1, Rl + OB + 2);
+            const int glo = (wlo + shift) >> 2, ghi = (whi + shift) >> 2;
+            const int nt = (ghi - glo + 60) / 60;
+            int hitl[2] = {OB, OB};                              // first level of the block at which the aligner reached the end
+#pragma unroll
+            for (int job = 0; job < 2; job++) {
+                const LP P = (LP)(lds_seq + (job ? a.max_words : 0) + 1);
+                const int base = job * width;
+                for (int ti = 0; ti < nt; ti++) {
+                    const int g = glo + ti * 60 + lane - 2;
+                    const bool owned = (lane >= 2) && (lane < 62) && (g <= ghi);
+                    const int k0 = (g << 2) - shift;
+                    const unsigned idx0 = (unsigned)(base + (g << 2));
+                    const V4<OT> v1 = ld4<OT>(pM1, idx0), v2 = ld4<OT>(pM2, idx0), vi = ld4<OT>(pI, idx0), vd = ld4<OT>(pD, idx0);
+                    int m1[4], m2[4], i1[4], d1[4];
+                    unsigned lim[4];
+#pragma unroll
+                    for (int qq = 0; qq < 4; qq++) {
+                        m1[qq] = (int)v1[qq]; m2[qq] = (int)v2[qq]; i1[qq] = (int)vi[qq]; d1[qq] = (int)vd[qq];
+                        lim[qq] = (unsigned)max(min(tlen, plen + k0 + qq), -1);
+                    }
+                    bool hit_now = false;
+                    int hit_at = OB;
+#pragma unroll
+                    for (int j = 0; j < OB; j++) {
+                        const int s = s0 + j;
+                        const int R = reach(pen, s, SR_C_M);
+                        const int klo = max(-plen, -R), khi = min(tlen, R);
+                        // sources: the k-1 / k+1 cells of max(M[s-2], I[s-1]) and max(M[s-2], D[s-1])
+                        int ti_[4], td_[4];
+#pragma unroll
+                        for (int qq = 0; qq < 4; qq++) { ti_[qq] = max(m2[qq], i1[qq]); td_[qq] = max(m2[qq], d1[qq]); }
+                        const int tiL = o_lane_left(ti_[3]), tdR = o_lane_right(td_[0]);
+                        int mv[4], iv[4], dv[4];
+#pragma unroll
+                        for (int qq = 0; qq < 4; qq++) {
+                            const int k = k0 + qq;
+                            const bool inr = (k >= klo) && (k <= khi);
+                            int in_ = bnd(((qq == 0) ? tiL : ti_[qq == 0 ? 0 : qq - 1]) + 1, lim[qq]);
+                            int dn_ = bnd((qq == 3) ? tdR : td_[qq == 3 ? 3 : qq + 1], lim[qq]);
+                            int m = bnd(m1[qq] + 1, lim[qq]);
+                            m = max(m, max(in_, dn_));
+                            if (!inr) { m = NULLV; in_ = NULLV; dn_ = NULLV; }
+                            if (s == 0) { m = (inr && k == 0) ? 0 : NULLV; in_ = NULLV; dn_ = NULLV; }
+                            mv[qq] = m; iv[qq] = in_; dv[qq] = dn_;
+                        }
+                        // extension of every valid cell of the wave (halo lanes feed owned cells of later levels)
+                        int more = 0;
+#pragma unroll
+                        for (int qq = 0; qq < 4; qq++) {
+                            const bool valid = mv[qq] >= 0;
+                            const int h = valid ? mv[qq] : 0, v = valid ? mv[qq] - (k0 + qq) : 0;
+                            const int nn = valid ? min(plen - v, tlen - h) : 0;
+                            const uint32_t xw = win_fwd(P, v) ^ win_fwd(T, h);
+                            const unsigned z = (unsigned)(__ffs((int)xw) - 1) >> SR_SYM_LOG;
+                            mv[qq] += (int)min(min(z, (unsigned)SR_WIN), (unsigned)nn);
+                            more |= (xw == 0u && nn > SR_WIN) ? (1 << qq) : 0;
+                        }
+                        unsigned long long pend[4];
+#pragma unroll
+                        for (int qq = 0; qq < 4; qq++) pend[qq] = __ballot((more >> qq) & 1);
+                        while ((pend[0] | pend[1] | pend[2] | pend[3]) != 0ull) {
+#pragma unroll
+                            for (int qq = 0; qq < 4; qq++) {
+                                if (pend[qq] == 0ull) continue;
+                                const bool on = (more >> qq) & 1;
+                                const int h = on ? mv[qq] : 0, v = on ? mv[qq] - (k0 + qq) : 0;
+                                const int nn = on ? min(plen - v, tlen - h) : 0;
+                                const uint32_t xw = win_fwd(P, v) ^ win_fwd(T, h);
+                                const unsigned z = (unsigned)(__ffs((int)xw) - 1) >> SR_SYM_LOG;
+                                mv[qq] += (int)min(min(z, (unsigned)SR_WIN), (unsigned)nn);
+                                if (!(xw == 0u && nn > SR_WIN)) more &= ~(1 << qq);
+                                pend[qq] = __ballot((more >> qq) & 1);
+                            }
+                        }
+                        if (!hit_now) {
+#pragma unroll
+                            for (int qq = 0; qq < 4; qq++)
+                                hit_now |= owned && (k0 + qq) == kend && (k0 + qq) >= klo && (k0 + qq) <= khi && mv[qq] >= tlen;
+                            if (hit_now) hit_at = j;
+                        }
+#pragma unroll
+                        for (int qq = 0; qq < 4; qq++) { m2[qq] = m1[qq]; m1[qq] = mv[qq]; i1[qq] = iv[qq]; d1[qq] = dv[qq]; }
+                    }
+                    if (owned) {
+                        V4<OT> a1, a2, ai, ad;
+#pragma unroll
+                        for (int qq = 0; qq < 4; qq++) { a1[qq] = (OT)m1[qq]; a2[qq] = (OT)m2[qq]; ai[qq] = (OT)i1[qq]; ad[qq] = (OT)d1[qq]; }
+                        st4<OT>(oM1, idx0, a1); st4<OT>(oM2, idx0, a2); st4<OT>(oI, idx0, ai); st4<OT>(oD, idx0, ad);
+                    }
+                    // (min over the lanes: exactly one lane owns the end diagonal)
+                    const unsigned long long hm = __ballot(hit_now);
+                    if (hm) hitl[job] = min(hitl[job], __shfl(hit_at, __ffsll((long long)hm) - 1, 64));
+                }
+            }
+            __syncthreads();                                    // one wave: workgroup-scope fence, the block's rows are visible
+            // per level the reference checks the forward aligner first
+            const int done = min(hitl[0], hitl[1]);
+            const int lv = min(OB - 1, done);
+            for (int j = 0; j <= lv; j++) {                      // level statistics as the level-by-level kernel counts them
+                const int R = reach(pen, s0 + j, SR_C_M);
+                cells += 2ull * (unsigned long long)(min(tlen, R) - max(-plen, -R) + 1);
+                steps += 2;
+            }
+            if (done < OB) {
+                if (hitl[0] <= hitl[1]) fwd = s0 + hitl[0];
+                else { rev = s0 + hitl[1]; is_rev = 1; }
+                break;
+            }
+            if (s0 + OB - 1 > smax) { err |= SR_DEV_ERR_SCORE_BOUND; break; }
+        }
+        if (lane == 0) {
+            a.is_reverse[pair] = is_rev ? 1 : 0;
+            a.ori_fwd[pair] = fwd; a.ori_rev[pair] = rev;
+        }
+    }
+    if (lane == 0) {
+        if (cells) { atomicAdd(&a.counters[0], cells); atomicAdd(&a.counters[6], cells); }
+        if (steps) atomicAdd(&a.counters[1], steps);
+        if (err) atomicOr(a.error_flag, err);
+    }
+}
+#undef OB
+
 }  // namespace
 using namespace SR_NS;
 extern "C" int SRK_NAME(srk_orient)(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, void *stream) {
     hipStream_t st = (hipStream_t)stream;
+    const bool blocked = !a->ori.two && a->ori.x == 1 && a->ori.o1 == 1 && a->ori.e1 == 1 && !getenv("SR_ORIENT_LEVELS");
+    if (blocked) {
+        if (lds_bytes > 32 * 1024) {
+            hipError_t e = off16 ? hipFuncSetAttribute((const void *)sr_orient_blk_kernel<int16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)
+                                 : hipFuncSetAttribute((const void *)sr_orient_blk_kernel<int32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e != hipSuccess) return (int)e;
+        }
+        if (off16) hipLaunchKernelGGL((sr_orient_blk_kernel<int16_t>), dim3(nwg), dim3(64), lds_bytes, st, *a);
+        else hipLaunchKernelGGL((sr_orient_blk_kernel<int32_t>), dim3(nwg), dim3(64), lds_bytes, st, *a);
+        return (int)hipGetLastError();
+    }
     if (off16) {
         if (lds_bytes > 32 * 1024) {
             hipError_t e = hipFuncSetAttribute((const void *)sr_orient_kernel<int16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
