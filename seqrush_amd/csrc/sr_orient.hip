@@ -243,17 +243,32 @@ __global__ void __launch_bounds__(64, 4) sr_orient_blk_kernel(SrAlignArgs a) {
                             if (s == 0) { m = (inr && k == 0) ? 0 : NULLV; in_ = NULLV; dn_ = NULLV; }
                             mv[qq] = m; iv[qq] = in_; dv[qq] = dn_;
                         }
-                        // extension of every valid cell of the wave (halo lanes feed owned cells of later levels)
+                        // extension of every cell of the wave (halo lanes feed owned cells of later levels).  The eight
+                        // window reads are in flight together; a NULL cell runs through the same code (its reads land
+                        // anywhere in or outside the LDS allocation, its value stays negative and is reset by bnd() at
+                        // the next level), only the "longer than a window" flag looks at validity.
                         int more = 0;
+                        {
+                            uint32_t pl[4], ph[4], tl[4], th[4];
 #pragma unroll
-                        for (int qq = 0; qq < 4; qq++) {
-                            const bool valid = mv[qq] >= 0;
-                            const int h = valid ? mv[qq] : 0, v = valid ? mv[qq] - (k0 + qq) : 0;
-                            const int nn = valid ? min(plen - v, tlen - h) : 0;
-                            const uint32_t xw = win_fwd(P, v) ^ win_fwd(T, h);
-                            const unsigned z = (unsigned)(__ffs((int)xw) - 1) >> SR_SYM_LOG;
-                            mv[qq] += (int)min(min(z, (unsigned)SR_WIN), (unsigned)nn);
-                            more |= (xw == 0u && nn > SR_WIN) ? (1 << qq) : 0;
+                            for (int qq = 0; qq < 4; qq++) {
+                                const int h = mv[qq], v = mv[qq] - (k0 + qq);
+                                pl[qq] = P[v >> SR_WIN_LOG]; ph[qq] = P[(v >> SR_WIN_LOG) + 1];
+                                tl[qq] = T[h >> SR_WIN_LOG]; th[qq] = T[(h >> SR_WIN_LOG) + 1];
+                            }
+                            asm volatile("; 8 windows in flight" : "+v"(pl[0]), "+v"(ph[0]), "+v"(pl[1]), "+v"(ph[1]), "+v"(pl[2]), "+v"(ph[2]), "+v"(pl[3]), "+v"(ph[3]),
+                                                                    "+v"(tl[0]), "+v"(th[0]), "+v"(tl[1]), "+v"(th[1]), "+v"(tl[2]), "+v"(th[2]), "+v"(tl[3]), "+v"(th[3]));
+#pragma unroll
+                            for (int qq = 0; qq < 4; qq++) {
+                                const int h = mv[qq], v = mv[qq] - (k0 + qq);
+                                const int nn = (int)lim[qq] - h;
+                                const uint32_t xw = __builtin_amdgcn_alignbit(ph[qq], pl[qq], (uint32_t)v << SR_SYM_LOG) ^
+                                                    __builtin_amdgcn_alignbit(th[qq], tl[qq], (uint32_t)h << SR_SYM_LOG);
+                                const unsigned z = (unsigned)(__ffs((int)xw) - 1) >> SR_SYM_LOG;
+                                const bool valid = h >= 0;
+                                mv[qq] += (int)min(min(z, (unsigned)SR_WIN), (unsigned)nn);
+                                more |= (valid && xw == 0u && nn > SR_WIN) ? (1 << qq) : 0;
+                            }
                         }
                         unsigned long long pend[4];
 #pragma unroll
