@@ -64,6 +64,7 @@ for seed in range(int(sys.argv[3]) if len(sys.argv) > 3 else 80):
     if rng.random() < 0.3: env["SR_PREORIENT"] = rng.choice(["0", "1"])
     if rng.random() < 0.3: env["SR_ALIGN_THREADS"] = rng.choice(["64", "128", "512"])
     if rng.random() < 0.2: env["SR_BLK_LEVELS"] = "5"
+    if rng.random() < 0.35: env["SR_NWG"] = rng.choice(["1", "2", "3"])      # several pairs per workgroup
     if rng.random() < 0.2: env["SR_CIGAR_ARENA_OPS"] = str(2 * L + 50)
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
