@@ -579,7 +579,8 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
     // impl 2 also stages the reversed target (4 regions) and has ~16 KB of static LDS
     // (the blocked kernel has its own ring depth limit, checked by srk_align_blk_supports: it does not inherit the
     // level-synchronous kernel's 32-slot limit)
-    if (kblock > 0 && (long long)max_words * 16 + 40 * 1024 <= 160 * 1024) impl = 2;
+    // (the blocked kernel wraps its LDS window addresses into 128 KB: static tables + four sequence copies must fit below)
+    if (kblock > 0 && (long long)max_words * 16 + 24 * 1024 <= 128 * 1024) impl = 2;
     if (const char *e = getenv("SR_ALIGN_IMPL")) impl = std::min(impl, std::max(0, atoi(e)));
     if (impl == 0 && sm.bits != 2)
         return fail(SR_ERR_UNSUPPORTED, "penalties with scope > 31 run on sr_align_kernel, which is built for upper-case ACGT input only");

@@ -252,9 +252,15 @@ __global__ void __launch_bounds__(64, 4) sr_orient_blk_kernel(SrAlignArgs a) {
                             uint32_t pl[4], ph[4], tl[4], th[4];
 #pragma unroll
                             for (int qq = 0; qq < 4; qq++) {
+                                // (byte addresses wrapped into the first 128 KB: a NULL cell points anywhere, and LDS reads far
+                                // outside the physical LDS are not harmless, see sr_align_blk.inc win_sym)
                                 const int h = mv[qq], v = mv[qq] - (k0 + qq);
-                                pl[qq] = P[v >> SR_WIN_LOG]; ph[qq] = P[(v >> SR_WIN_LOG) + 1];
-                                tl[qq] = T[h >> SR_WIN_LOG]; th[qq] = T[(h >> SR_WIN_LOG) + 1];
+                                typedef uint32_t __attribute__((ext_vector_type(2), aligned(4))) W2;
+                                const uint32_t ap = ((uint32_t)(uintptr_t)P + (uint32_t)((v >> SR_WIN_LOG) << 2)) & 0x1fffcu;
+                                const uint32_t at = ((uint32_t)(uintptr_t)T + (uint32_t)((h >> SR_WIN_LOG) << 2)) & 0x1fffcu;
+                                const W2 wp = *(const W2 __attribute__((address_space(3))) *)(uintptr_t)ap;
+                                const W2 wt = *(const W2 __attribute__((address_space(3))) *)(uintptr_t)at;
+                                pl[qq] = wp.x; ph[qq] = wp.y; tl[qq] = wt.x; th[qq] = wt.y;
                             }
                             asm volatile("; 8 windows in flight" : "+v"(pl[0]), "+v"(ph[0]), "+v"(pl[1]), "+v"(ph[1]), "+v"(pl[2]), "+v"(ph[2]), "+v"(pl[3]), "+v"(ph[3]),
                                                                     "+v"(tl[0]), "+v"(th[0]), "+v"(tl[1]), "+v"(th[1]), "+v"(tl[2]), "+v"(th[2]), "+v"(tl[3]), "+v"(th[3]));
