@@ -192,6 +192,8 @@ struct sr_ctx {
     unsigned long long *d_counters = nullptr;
     int *d_error = nullptr;
     uint32_t *d_queue = nullptr, *d_oqueue = nullptr, *d_order = nullptr;
+    uint64_t *d_okeys = nullptr, *d_okeys2 = nullptr;   // cost-ordered dequeue after the orientation kernel (sr_order.hip)
+    uint32_t *d_ovals = nullptr; void *d_otemp = nullptr; size_t otemp_bytes = 0;
     uint64_t *d_cbase = nullptr;                   // [np + nbatch]: batch b starts at batch_first[b] + b, values relative to its arena
     uint8_t *d_bases = nullptr;                    // raw bytes of all sequences (sketching, graph induction)
     int onwg = 0;                      // workgroups (= waves) of the orientation kernel, 0 = orientation inside the alignment kernel
@@ -726,6 +728,13 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
                 if ((r = dev_alloc(c, &d, oring_bytes))) return r; a.oring = d;
                 if ((r = dev_alloc(c, &d, sizeof(uint32_t)))) return r; c->d_oqueue = (uint32_t *)d;
                 a.oring_wg_stride = oring_wg; a.orow = orow; a.oqueue = c->d_oqueue; a.pre_oriented = 1;
+                if (!getenv("SR_NO_REORDER")) {       // dequeue order from the orientation scores, per batch
+                    c->otemp_bytes = srk_order_temp_bytes(max_batch_pairs);
+                    if ((r = dev_alloc(c, &d, (uint64_t)max_batch_pairs * 8))) return r; c->d_okeys = (uint64_t *)d;
+                    if ((r = dev_alloc(c, &d, (uint64_t)max_batch_pairs * 8))) return r; c->d_okeys2 = (uint64_t *)d;
+                    if ((r = dev_alloc(c, &d, (uint64_t)max_batch_pairs * 4))) return r; c->d_ovals = (uint32_t *)d;
+                    if ((r = dev_alloc(c, &d, std::max<size_t>(c->otemp_bytes, 16)))) return r; c->d_otemp = d;
+                }
                 c->onwg = onwg; c->olds_bytes = (size_t)max_words * 3 * 4;
             }
         }
@@ -843,6 +852,10 @@ static int enqueue_align_batch(sr_ctx *c, uint32_t b) {
         HIPCHK(hipEventRecord(*e0, c->stream));
         r = srk_orient(&a, std::min<int>(c->onwg, (int)a.npairs), c->olds_bytes, c->off16, c->stream);
         if (r) return fail(SR_ERR_HIP, std::string("orientation kernel launch failed: ") + hipGetErrorString((hipError_t)r));
+        if (c->d_okeys && a.order) {             // longest predicted alignment first (orientation score x length)
+            r = srk_order(&a, c->d_okeys, c->d_okeys2, c->d_ovals, c->d_otemp, c->otemp_bytes, (uint32_t *)a.order, c->stream);
+            if (r) return fail(SR_ERR_HIP, std::string("dequeue-order sort failed: ") + hipGetErrorString((hipError_t)r));
+        }
         HIPCHK(hipEventRecord(*e1, c->stream));
         c->ev_used[4]++;
     }

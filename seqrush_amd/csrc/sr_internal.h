@@ -135,6 +135,10 @@ int srk_merge(unsigned long long *nodes, uint64_t uf_size, const unsigned long l
               uint32_t count, int *error_flag, void *stream);
 int srk_align_max_lds(void);
 int srk_orient(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, void *stream);
+// sr_order.hip: dequeue order of a batch by predicted cost (orientation score x length), sorted on the device
+size_t srk_order_temp_bytes(uint32_t n);
+int srk_order(const SrAlignArgs *a, uint64_t *keys_in, uint64_t *keys_out, uint32_t *vals_in, void *temp, size_t temp_bytes,
+              uint32_t *order_out, void *stream);
 int srk_graph_induce(const unsigned long long *labels, const uint8_t *bases, const uint8_t *islast,
                      uint64_t N, uint64_t uf_size, unsigned long long *first, uint32_t *flag, uint32_t *nid,
                      uint32_t *steps, uint8_t *node_base, unsigned long long *hkeys, uint32_t *hvals,
