@@ -583,7 +583,10 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
     // level-synchronous kernel's 32-slot limit)
     // (the blocked kernel wraps its LDS window addresses into 128 KB: static tables + four sequence copies must fit below)
     if (kblock > 0 && (long long)max_words * 16 + 24 * 1024 <= 128 * 1024) impl = 2;
-    if (const char *e = getenv("SR_ALIGN_IMPL")) impl = std::min(impl, std::max(0, atoi(e)));
+    if (const char *e = getenv("SR_ALIGN_IMPL")) {       // (a request for the level-per-pass kernel falls through to kernel 0 when its ring is too shallow)
+        const int want = std::max(0, atoi(e)), bfs_ok = std::max(pen.scope, ori.scope) + 1 <= 32;
+        if (want < impl) impl = (want == 1 && !bfs_ok) ? 0 : want;
+    }
     if (impl == 0 && sm.bits != 2)
         return fail(SR_ERR_UNSUPPORTED, "penalties with scope > 31 run on sr_align_kernel, which is built for upper-case ACGT input only");
     if (impl == 2) c->lds_bytes = (size_t)max_words * 4 * 4 + 16;      // (+ read slack of a two-window extension step)
