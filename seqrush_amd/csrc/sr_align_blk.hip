@@ -36,14 +36,14 @@ static int launch_blk3(const SrAlignArgs *a, int nwg, size_t lds_bytes, hipStrea
 }
 // exact-penalty instance: mismatch 5, o1 + e1 = 10 (the reference's default -S 0,5,8,2,24,1 and the one-piece 0,5,8,2):
 // blocks of 10 levels (sr_align_blk.inc blk_tile)
-template <typename OT, int NT, bool TWO, bool PROF = false>
+template <typename OT, int NT, bool TWO, bool PROF = false, typename RT = OT>
 static int launch_blk10(const SrAlignArgs *a, int nwg, size_t lds_bytes, hipStream_t st) {
     if (lds_bytes > 16 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)sr_align_blk_kernel<OT, NT, TWO, 10, 2, 1, PROF, 5, 10>,
+        hipError_t e = hipFuncSetAttribute((const void *)sr_align_blk_kernel<OT, NT, TWO, 10, 2, 1, PROF, 5, 10, RT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL((sr_align_blk_kernel<OT, NT, TWO, 10, 2, 1, PROF, 5, 10>), dim3(nwg), dim3(NT), lds_bytes, st, *a);
+    hipLaunchKernelGGL((sr_align_blk_kernel<OT, NT, TWO, 10, 2, 1, PROF, 5, 10, RT>), dim3(nwg), dim3(NT), lds_bytes, st, *a);
     return (int)hipGetLastError();
 }
 // penalty sets this build has a blocked instance for (host side asks before choosing impl 2): levels per block
@@ -86,6 +86,9 @@ extern "C" int SRK_NAME(srk_align_blk)(const SrAlignArgs *a, int nwg, size_t lds
 #endif
             return two ? launch_blk10<int16_t, 256, true>(a, nwg, lds_bytes, st) : launch_blk10<int16_t, 256, false>(a, nwg, lds_bytes, st);
         }
+        // 32-bit searches with the ring stored as uint16 (offset + 8192): longest sequence < 57 k (host: ring_u16)
+        if (a->ring_u16) return two ? launch_blk10<int32_t, 256, true, false, uint16_t>(a, nwg, lds_bytes, st)
+                                    : launch_blk10<int32_t, 256, false, false, uint16_t>(a, nwg, lds_bytes, st);
         return two ? launch_blk10<int32_t, 256, true>(a, nwg, lds_bytes, st) : launch_blk10<int32_t, 256, false>(a, nwg, lds_bytes, st);
     }
     if (off16) {

@@ -629,7 +629,12 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
     // impl 2: chunk-major ring (sr_align_blk.inc KRows): 256-cell pieces of all 5 * depth + 2 rows together, + 2 pieces of read slack
     if (impl == 2) bring_wg = ((uint64_t)brow / 256 + 2ULL) * ((uint64_t)kdepth * 5 + 2ULL) * 256ULL + 1024;
     // (the blocked kernel addresses a workgroup's rows as base + 32-bit byte offset)
-    if (impl == 2 && bring_wg * osz >= (1ULL << 32)) return fail(SR_ERR_UNSUPPORTED, "sequences too long for the device row workspace (4 GB per workgroup)");
+    // 32-bit searches below 57 k keep their ring as uint16 (offset + 8192): half the row bytes (C5 is bound by them).
+    // The exact 10-level instance at 256 threads has that build; SR_RING_U16=0 keeps 32-bit rows.
+    const char *ru = getenv("SR_RING_U16");
+    const int ring_u16 = (impl == 2 && !c->off16 && kblock == 10 && c->nthreads >= 256 && maxlen <= 57000 && !(ru && atoi(ru) == 0)) ? 1 : 0;
+    const size_t rsz = ring_u16 ? 2 : osz;                 // bytes per ring cell (the base-case history keeps osz)
+    if (impl == 2 && bring_wg * rsz >= (1ULL << 32)) return fail(SR_ERR_UNSUPPORTED, "sequences too long for the device row workspace (4 GB per workgroup)");
     int bbase_jobs = wave_wg ? (c->nthreads == 64 ? 4 : 8) : 16;
     if (const char *e = getenv("SR_BFS_BASE_JOBS")) bbase_jobs = std::max(1, std::min(16, atoi(e)));
     const uint64_t bhist_wg = ((uint64_t)hist_levels * 5 + 1) * (uint64_t)bbase_jobs * (uint64_t)hist_w + 1024;
@@ -637,7 +642,7 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
     const uint64_t bbt_wg = (uint64_t)bbase_jobs * SR_BFS_BTCAP * 4;           // bytes
     // impl 2: every diagonal of every level of a block can be a breakpoint candidate at worst
     const uint64_t bcl_wg = (impl == 2) ? (uint64_t)std::max(kblock, 1) * (uint64_t)brow : 0;
-    const uint64_t per_wg_bytes = impl ? (bring_wg + bhist_wg) * osz + bseg_wg + bbt_wg + bcl_wg * 4 + (impl == 2 ? 32 * SR_BLK_MAK_SLOTS * 4 : 0)
+    const uint64_t per_wg_bytes = impl ? bring_wg * rsz + bhist_wg * osz + bseg_wg + bbt_wg + bcl_wg * 4 + (impl == 2 ? 32 * SR_BLK_MAK_SLOTS * 4 : 0)
                                        : (ring_wg + hist_wg) * osz;
     // ---- memory budget: every buffer counted.  fixed = union-find arrays + per-pair arrays;
     //      then the CIGAR arena (worst case |q|+|t|+2 ops per pair; pairs run in batches that reuse it), the
@@ -701,15 +706,15 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
     if ((r = dev_alloc(c, &d, sizeof(uint32_t)))) return r; c->d_queue = (uint32_t *)d;
     uint64_t oring_bytes = 0;
     if (impl) {
-        if ((r = dev_alloc(c, &d, (uint64_t)nwg * bring_wg * osz))) return r; a.bring = d;
+        if ((r = dev_alloc(c, &d, (uint64_t)nwg * bring_wg * rsz))) return r; a.bring = d;
         if ((r = dev_alloc(c, &d, (uint64_t)nwg * bhist_wg * osz))) return r; a.bhist = d;
         // (tests: the kernels must not depend on what the row workspaces held before -- poison them with plausible offsets)
         if (const char *e = getenv("SR_POISON_ROWS")) {
             const int v = atoi(e);
-            if (osz == 2) { HIPCHK(hipMemsetD16Async((hipDeviceptr_t)a.bring, (unsigned short)v, (size_t)nwg * bring_wg, c->stream));
-                            HIPCHK(hipMemsetD16Async((hipDeviceptr_t)a.bhist, (unsigned short)v, (size_t)nwg * bhist_wg, c->stream)); }
-            else { HIPCHK(hipMemsetD32Async((hipDeviceptr_t)a.bring, v, (size_t)nwg * bring_wg, c->stream));
-                   HIPCHK(hipMemsetD32Async((hipDeviceptr_t)a.bhist, v, (size_t)nwg * bhist_wg, c->stream)); }
+            if (rsz == 2) HIPCHK(hipMemsetD16Async((hipDeviceptr_t)a.bring, (unsigned short)(ring_u16 ? v + 8192 : v), (size_t)nwg * bring_wg, c->stream));
+            else HIPCHK(hipMemsetD32Async((hipDeviceptr_t)a.bring, v, (size_t)nwg * bring_wg, c->stream));
+            if (osz == 2) HIPCHK(hipMemsetD16Async((hipDeviceptr_t)a.bhist, (unsigned short)v, (size_t)nwg * bhist_wg, c->stream));
+            else HIPCHK(hipMemsetD32Async((hipDeviceptr_t)a.bhist, v, (size_t)nwg * bhist_wg, c->stream));
         }
         if ((r = dev_alloc(c, &d, (uint64_t)nwg * bseg_wg))) return r; a.bseg = (int *)d;
         if ((r = dev_alloc(c, &d, (uint64_t)nwg * bbt_wg))) return r; a.bbt = (uint32_t *)d;
@@ -767,7 +772,7 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
     a.ring_wg_stride = ring_wg; a.ring_dir_stride = ring_dir; a.ring_cap = ring_cap; a.ring_scope = ring_scope; a.ring_hot = ring_hot;
     a.hist_wg_stride = hist_wg; a.hist_w = hist_w; a.hist_levels = hist_levels;
     { const char *pt_ = getenv("SR_PROFILE_TICKS"); a.profile_ticks = (pt_ && atoi(pt_) != 0) ? 1 : 0; }
-    a.impl = impl; a.kdepth = kdepth; a.kblock = kblock; a.lazy_id = lazy_id; a.bring_wg_stride = bring_wg; a.brow = brow; a.bhist_wg_stride = bhist_wg; a.bbase_jobs = bbase_jobs;
+    a.impl = impl; a.kdepth = kdepth; a.kblock = kblock; a.lazy_id = lazy_id; a.ring_u16 = ring_u16; a.bring_wg_stride = bring_wg; a.brow = brow; a.bhist_wg_stride = bhist_wg; a.bbase_jobs = bbase_jobs;
     a.cigar_base = c->d_cbase; a.counters = c->d_counters; a.error_flag = c->d_error;
     SrUniteArgs &u = c->ua;
     memset(&u, 0, sizeof(u));
@@ -784,7 +789,7 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
                  "\"base_history_bytes_per_workgroup\": %llu, \"workspace_bytes\": %llu, \"cigar_arena_bytes\": %llu, "
                  "\"orientation_ring_bytes\": %llu, \"union_find_bytes\": %llu, \"device_free_bytes_at_load\": %zu}",
                  np, nbatch, sm.bits, osz, impl, nwg, c->nthreads, wg_per_cu, c->lds_bytes,
-                 (unsigned long long)((impl ? bring_wg : ring_wg) * osz), (unsigned long long)((impl ? bhist_wg : hist_wg) * osz),
+                 (unsigned long long)(impl ? bring_wg * rsz : ring_wg * osz), (unsigned long long)((impl ? bhist_wg : hist_wg) * osz),
                  (unsigned long long)((uint64_t)nwg * per_wg_bytes), (unsigned long long)(arena_ops * 4), (unsigned long long)oring_bytes,
                  (unsigned long long)(3ULL * c->uf_size * 8), free_b);
         c->workspace_report = buf;
