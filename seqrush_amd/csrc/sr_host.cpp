@@ -784,11 +784,11 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
     {
         char buf[640];
         snprintf(buf, sizeof(buf),
-                 "{\"pairs\": %u, \"batches\": %u, \"symbol_bits\": %d, \"offset_bytes\": %zu, \"kernel_impl\": %d, \"workgroups\": %d, "
+                 "{\"pairs\": %u, \"batches\": %u, \"symbol_bits\": %d, \"offset_bytes\": %zu, \"ring_cell_bytes\": %zu, \"kernel_impl\": %d, \"workgroups\": %d, "
                  "\"threads_per_workgroup\": %d, \"workgroups_per_cu\": %d, \"lds_dynamic_bytes\": %zu, \"ring_bytes_per_workgroup\": %llu, "
                  "\"base_history_bytes_per_workgroup\": %llu, \"workspace_bytes\": %llu, \"cigar_arena_bytes\": %llu, "
                  "\"orientation_ring_bytes\": %llu, \"union_find_bytes\": %llu, \"device_free_bytes_at_load\": %zu}",
-                 np, nbatch, sm.bits, osz, impl, nwg, c->nthreads, wg_per_cu, c->lds_bytes,
+                 np, nbatch, sm.bits, osz, impl == 2 ? rsz : osz, impl, nwg, c->nthreads, wg_per_cu, c->lds_bytes,
                  (unsigned long long)(impl ? bring_wg * rsz : ring_wg * osz), (unsigned long long)((impl ? bhist_wg : hist_wg) * osz),
                  (unsigned long long)((uint64_t)nwg * per_wg_bytes), (unsigned long long)(arena_ops * 4), (unsigned long long)oring_bytes,
                  (unsigned long long)(3ULL * c->uf_size * 8), free_b);

@@ -166,9 +166,16 @@ def test_several_pairs_per_workgroup(gpu, monkeypatch, name, recs, kw, env):
     check_parity(recs, **kw)
 
 
-def test_50kb_pair_int32_offsets(gpu):
-    """sequences > 32 kb take the 32-bit offset kernel instantiation (LDS staging of 50 kb sequences)"""
-    recs = synth.snp_family(2, 40000, 0.01, 61)
+@pytest.mark.parametrize("length,env", [(40000, {}), (40000, {"SR_RING_U16": "0"}), (60000, {})])
+def test_50kb_pair_int32_offsets(gpu, monkeypatch, length, env):
+    """sequences > 32 kb take the 32-bit offset kernel instantiation (LDS staging of 50 kb sequences); below 57 k its
+    ring is stored as uint16 (offset + 8192), above -- or with SR_RING_U16=0 -- as int32"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    recs = synth.snp_family(2, length, 0.01 if length <= 40000 else 0.004, 61)
+    ss = SeqSet(recs); ctx = Context(0); ctx.load(ss, Params())
+    rep = ctx.workspace_report(); ctx.close()
+    assert rep["offset_bytes"] == 4 and rep["ring_cell_bytes"] == (2 if length <= 57000 and not env else 4)
     check_parity(recs)
 
 
