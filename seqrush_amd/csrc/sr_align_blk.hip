@@ -87,6 +87,8 @@ extern "C" int SRK_NAME(srk_align_blk)(const SrAlignArgs *a, int nwg, size_t lds
             return two ? launch_blk10<int16_t, 256, true>(a, nwg, lds_bytes, st) : launch_blk10<int16_t, 256, false>(a, nwg, lds_bytes, st);
         }
         // 32-bit searches with the ring stored as uint16 (offset + 8192): longest sequence < 57 k (host: ring_u16)
+        if (a->ring_u16 && nthreads == 512) return two ? launch_blk10<int32_t, 512, true, false, uint16_t>(a, nwg, lds_bytes, st)
+                                                       : launch_blk10<int32_t, 512, false, false, uint16_t>(a, nwg, lds_bytes, st);
         if (a->ring_u16) return two ? launch_blk10<int32_t, 256, true, false, uint16_t>(a, nwg, lds_bytes, st)
                                     : launch_blk10<int32_t, 256, false, false, uint16_t>(a, nwg, lds_bytes, st);
         return two ? launch_blk10<int32_t, 256, true>(a, nwg, lds_bytes, st) : launch_blk10<int32_t, 256, false>(a, nwg, lds_bytes, st);

@@ -602,6 +602,13 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
     if (wave_wg) wg_per_cu = c->nthreads == 64 ? 16 : 8;
     const size_t lds_per_wg = c->lds_bytes + (wave_wg ? 4 : impl == 2 ? 20 : impl ? 28 : 8) * 1024;
     wg_per_cu = (int)std::min<size_t>((size_t)wg_per_cu, std::max<size_t>(1, (160 * 1024) / lds_per_wg));
+    // long sequences: the four LDS copies leave room for two workgroups per CU (C5: 50 KB each) -- give each 8 waves, or
+    // the SIMDs hold two waves (C5 subset 3 507 -> 2 200 ms).  512-thread builds: int16 rows; 32-bit searches with the
+    // uint16 ring (exact instance below 57 k, see ring_u16)
+    if (impl == 2 && !wave_wg && wg_per_cu <= 2 && !getenv("SR_ALIGN_THREADS")) {
+        const char *ru_ = getenv("SR_RING_U16");
+        if (c->off16 || (kblock == 10 && maxlen <= 57000 && !(ru_ && atoi(ru_) == 0))) c->nthreads = 512;
+    }
     const int ring_scope = std::max(pen.scope, ori.scope);
     const int ring_cap = (int)((2 * maxlen + 3 + 7) & ~7ULL);
     int emax = std::max(pen.e1, ori.e1);
