@@ -79,7 +79,10 @@ extern "C" int SRK_NAME(srk_align_blk)(const SrAlignArgs *a, int nwg, size_t lds
     const bool two = a->pen.two != 0;
     if (a->kblock == 10) {
         if (off16) {
-            if (nthreads == 512) return two ? launch_blk10<int16_t, 512, true>(a, nwg, lds_bytes, st) : launch_blk10<int16_t, 512, false>(a, nwg, lds_bytes, st);
+#if SR_SYMBITS == 2
+            if (nthreads == 1024 && two) return launch_blk10<int16_t, 1024, true>(a, nwg, lds_bytes, st);    // fewer pairs than CUs
+#endif
+            if (nthreads >= 512) return two ? launch_blk10<int16_t, 512, true>(a, nwg, lds_bytes, st) : launch_blk10<int16_t, 512, false>(a, nwg, lds_bytes, st);
 #if SR_SYMBITS == 2
             // the instrumented instance (tick counters [6..15], SR_PROFILE_TICKS=1): default shape only
             if (a->profile_ticks && two) return launch_blk10<int16_t, 256, true, true>(a, nwg, lds_bytes, st);

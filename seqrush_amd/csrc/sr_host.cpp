@@ -596,7 +596,10 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
     // few pairs (e.g. the 1/8 shard of C2): one pair per workgroup leaves CUs short of waves, so give every
     // pair 8 waves instead of 4 (measured 31 -> 23 ms for 529 pairs of 5 kb)
     if (impl == 2 && (uint64_t)np <= 2ULL * (uint64_t)cus + (uint64_t)cus / 2) c->nthreads = 512;
-    if (const char *e = getenv("SR_ALIGN_THREADS")) { int v = atoi(e); if (impl ? (v == 128 || v == 256 || v == 512 || (v == 64 && impl == 2 && sm.bits == 2)) : (v == 64 || v == 128 || v == 256)) c->nthreads = v; }
+    // fewer pairs than CUs (C3: 144): a pair has a CU to itself -- 16 waves (C3 90.1 -> 69.2 ms)
+    if (impl == 2 && (uint64_t)np <= (uint64_t)cus) c->nthreads = 1024;
+    if (const char *e = getenv("SR_ALIGN_THREADS")) { int v = atoi(e); if (impl ? (v == 128 || v == 256 || v == 512 || (v == 1024 && impl == 2) || (v == 64 && impl == 2 && sm.bits == 2)) : (v == 64 || v == 128 || v == 256)) c->nthreads = v; }
+    if (c->nthreads == 1024 && !(impl == 2 && kblock == 10 && c->off16 && sm.bits == 2 && pen.two)) c->nthreads = 512;   // (the one 1024-thread build)
     if (impl == 2 && c->nthreads == 128 && kblock == 10 && !(sm.bits == 2 && c->off16)) kblock = 5;   // (no 128-thread 10-level instance there)
     const bool wave_wg = impl == 2 && (c->nthreads == 64 || (c->nthreads == 128 && kblock == 10));   // lean builds: 16 / 8 pairs per CU
     if (wave_wg) wg_per_cu = c->nthreads == 64 ? 16 : 8;
