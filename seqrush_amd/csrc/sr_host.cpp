@@ -782,7 +782,7 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
     a.ring_wg_stride = ring_wg; a.ring_dir_stride = ring_dir; a.ring_cap = ring_cap; a.ring_scope = ring_scope; a.ring_hot = ring_hot;
     a.hist_wg_stride = hist_wg; a.hist_w = hist_w; a.hist_levels = hist_levels;
     { const char *pt_ = getenv("SR_PROFILE_TICKS"); a.profile_ticks = (pt_ && atoi(pt_) != 0) ? 1 : 0; }
-    a.impl = impl; a.kdepth = kdepth; a.kblock = kblock; a.lazy_id = lazy_id; a.ring_u16 = ring_u16; a.bring_wg_stride = bring_wg; a.brow = brow; a.bhist_wg_stride = bhist_wg; a.bbase_jobs = bbase_jobs;
+    a.impl = impl; a.kdepth = kdepth; a.kblock = kblock; a.lazy_id = lazy_id; a.ring_u16 = ring_u16; a.ori_levels = getenv("SR_ORIENT_LEVELS") ? 1 : 0; a.bring_wg_stride = bring_wg; a.brow = brow; a.bhist_wg_stride = bhist_wg; a.bbase_jobs = bbase_jobs;
     a.cigar_base = c->d_cbase; a.counters = c->d_counters; a.error_flag = c->d_error;
     SrUniteArgs &u = c->ua;
     memset(&u, 0, sizeof(u));

@@ -90,6 +90,7 @@ struct SrAlignArgs {
     int lazy_id;               // impl 2: searches in phase 1 do not store the I/D rows only breakpoint detection reads
                                //   (kdepth >= 2 * scope + 2 * block + 2 so that they can be recomputed)
     int profile_ticks;         // impl 2: launch the instrumented instance (SR_PROFILE_TICKS=1)
+    int ori_levels;            // impl 2: in-kernel orientation level by level even for the default penalties (SR_ORIENT_LEVELS=1)
     int ring_u16;              // impl 2, 32-bit searches: the ring's cells are uint16 = offset + 8192 (longest sequence < 57 k)
     int *bmak;                 // impl 2: per workgroup [32 aligners][32 ring levels] max M antidiagonal (breakpoint pruning)
     // outputs
