@@ -10,14 +10,21 @@ packed sequences already resident in HBM.
 Rank 0 prints ONE JSON line.  The pair list is sharded over ranks (cost-balanced; strong scaling: the list is
 fixed); per-rank forests are merged with one RCCL all-gather of canonical u32 labels + replay-unite.
 
-roofline (dominant kernel = the alignment kernel):
-  achieved  = the kernel's row traffic, counted on the device lane access by lane access (every tile's row loads and
-              stores; sr_align_blk.inc), divided by the kernel's average launch time (hipEvents on its stream)
-  traffic   = HBM bytes per launch from the rocprofv3 PMC passes of the same command, FETCH_SIZE x 2.00 +
-              WRITE_SIZE x 1.00 (factors calibrated on this access shape by scripts/calib, profiles/r02_calibration.json)
-  valu_issue_frac = SQ_INSTS_VALU / (SIMDs x busy cycles x 0.5 wave-instructions per cycle and SIMD)
-The PMC-derived fields come from profiles/r02_counters.json (written by scripts/profile_round.sh in the same round);
-they are per launch of this same C2 workload.
+roofline (dominant kernel = the alignment kernel), all per launch, everything measured in THIS run unless tagged:
+  wf_level_diagonals   (score level, diagonal) units the kernel computed; every unit is five component cells (M I1 D1 I2 D2)
+  wf_cells             the same in SURVEY 8(d) units: sum over levels and components of the range width = 5 x the above
+                       (3 x for one-piece penalties)
+  achieved             SURVEY 8(d)'s algorithmic bytes of a ring that lives in HBM -- wf_cells x cell bytes x (1 write +
+                       ~1 effective read) -- divided by the kernel's average launch time (hipEvents on its stream)
+  bytes.tile_ideal     what the blocked tile needs at least: (row loads + row stores of one B-level tile) x cell bytes
+                       per level-diagonal (B = 10: 26 + 16 rows x 2 B / 10 levels = 8.4 B), x wf_level_diagonals
+  bytes.rows_counted   what the kernel really moved as rows: counted on the device lane access by lane access
+  bytes.lds_rows       the part of the rows that stayed in LDS (LDS-resident ring instance), not in rows_counted
+  traffic              HBM-side bytes per launch from the rocprofv3 PMC passes (FETCH_SIZE x 2.00 + WRITE_SIZE x 1.00,
+                       profiles/r02_calibration.json) -- only present when profiles/r03_counters.json was recorded for
+                       the same kernel name; tagged with the kernel time and box it was measured at (traffic_source)
+  unite                the second kernel: united bases x 24 B (2 parent loads + 1 CAS of 8-byte nodes) / its time
+`bound` is decided from this run's numbers only.
 """
 import argparse
 import json
@@ -100,6 +107,34 @@ def cpu_baseline(recs, pairs, total_pairs_label):
                      "usable_cpus": usable}}
 
 
+def host_stages(recs, ctx):
+    """the stages either side of the timed path, reported separately and never part of `value`:
+    FASTA parse (host loader, src/seqrush.rs:1801-1837), graph induction on the device + GFA text
+    (src/bidirected_builder.rs:17-289), compaction + renumber (host C++, src/bidirected_ops.rs:75-490) and the file write.
+    One measurement each on the union-find the timed steps left behind."""
+    import tempfile
+    from seqrush_amd.seqrush import load_sequences
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        fa = os.path.join(td, "in.fa")
+        with open(fa, "wb") as fh:
+            for n, sq in recs:
+                fh.write(b">" + n.encode() + b"\n" + sq + b"\n")
+        t0 = time.perf_counter(); seqs = load_sequences(fa); out["fasta_parse"] = (time.perf_counter() - t0) * 1e3
+        assert len(seqs) == len(recs)
+        t0 = time.perf_counter(); gfa, nn, ne = ctx.build_gfa(compact=False); t_ind = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter(); gfa_c, nc, ec = ctx.build_gfa(compact=True); t_cmp = (time.perf_counter() - t0) * 1e3
+        out["induction_and_gfa_text"] = t_ind
+        out["compaction_and_renumber"] = max(0.0, t_cmp - t_ind)        # the compact call repeats the induction
+        t0 = time.perf_counter()
+        with open(os.path.join(td, "out.gfa"), "w") as fh:
+            fh.write(gfa_c)
+        out["gfa_write"] = (time.perf_counter() - t0) * 1e3
+        out["nodes_edges_uncompacted"] = [nn, ne]; out["nodes_edges_compacted"] = [nc, ec]
+        out["gfa_bytes"] = len(gfa_c)
+    return out
+
+
 def build_config(name, nseq):
     from seqrush_amd import synth
     if name == "C2":
@@ -131,6 +166,7 @@ def main():
     ap.add_argument("--config", default="C2", choices=["C2", "C3", "C4", "C5"])
     ap.add_argument("--nseq", type=int, default=None, help="C2 / C5: number of sequences (default 64 / 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-stages", action="store_true", help="skip the FASTA / induction / compaction / GFA-write timings")
     args = ap.parse_args()
     if args.nseq is None:
         args.nseq = 256 if args.config == "C5" else 64
@@ -138,6 +174,21 @@ def main():
         args.steps = 1 if args.config == "C5" else 5
     if args.warmup is None:
         args.warmup = 0 if args.config == "C5" else 1
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` started plainly: one process per GPU under torch.distributed.run, started as a
+        # CHILD before anything in this process touches the GPU (never an exec); its stdout (rank 0's JSON line) and
+        # exit code are relayed
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.exit(subprocess.call(cmd, env=env))
 
     import torch
     import torch.distributed as dist
@@ -248,30 +299,58 @@ def main():
         a_ms = sum(align_ms) / len(align_ms)
         u_ms = sum(unite_ms) / len(unite_ms)
         o_ms = sum(orient_ms) / len(orient_ms) if orient_ms else None
-        ori_cells = cnt["ticks_orientation"] if orient_ms else 0      # [6] = the orientation kernel's cells
-        cells = cnt["wf_cells"] - ori_cells
-        row_bytes = cnt["row_bytes_loaded"] + cnt["row_bytes_stored"]
-        achieved = row_bytes / (a_ms * 1e-3) / 1e9 if a_ms > 0 else 0.0
-        pmc = {}
-        ppath = os.path.join(ROOT, "profiles", "r02_counters.json")
-        if world == 1 and args.config == "C2" and args.nseq == 64 and os.path.exists(ppath) and not os.environ.get("SR_BLK_LEVELS"):
+        ori_cells = cnt["ticks_orientation"] if orient_ms else 0      # [6] = the orientation kernel's level-diagonals
+        ldiag = cnt["wf_cells"] - ori_cells                           # (level, diagonal) units of the alignment kernel
+        ncomp = 5 if rep.get("two_piece", 1) else 3
+        cell_b = int(rep.get("ring_cell_bytes", 2))
+        cells_8d = ldiag * ncomp                                      # sum over levels and components
+        alg_bytes = cells_8d * cell_b * 2                             # 8(d): 1 write + ~1 effective read per cell
+        rows_counted = cnt["row_bytes_loaded"] + cnt["row_bytes_stored"]
+        lds_rows = cnt.get("lds_row_bytes", 0)
+        B = int(rep.get("block_levels", 1))
+        # row loads + stores of one B-level tile of the blocked kernel (sr_align_blk.inc): exact 10-level instance
+        # 26 + 16, generic 5-level instance 21 + 12; level-per-pass kernels: 7 source rows + 5 stored per level
+        tile_rows = {10: 42, 5: 33}.get(B, 12 * B)
+        tile_ideal = ldiag * tile_rows * cell_b / max(B, 1)
+        sec = a_ms * 1e-3
+        achieved = alg_bytes / sec / 1e9 if sec > 0 else 0.0
+        roof = {"bound": "hbm", "kernel": ctx.align_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": a_ms,
+                "achieved_is": "SURVEY 8(d) algorithmic bytes (wf_cells x cell bytes x 2) / kernel time; the kernel moves "
+                               "fewer bytes than that model (bytes.rows_counted): frac prices the model, rows_frac the rows",
+                "wf_level_diagonals": ldiag, "wf_cells": cells_8d, "components": ncomp, "cell_bytes": cell_b,
+                "bytes": {"algorithmic_8d": alg_bytes, "tile_ideal": tile_ideal, "rows_counted": rows_counted,
+                          "rows_loaded": cnt["row_bytes_loaded"], "rows_stored": cnt["row_bytes_stored"],
+                          "lds_rows": lds_rows,
+                          "rows_over_tile_ideal": rows_counted / tile_ideal if tile_ideal else None},
+                "rows_GBps": rows_counted / sec / 1e9 if sec > 0 else None,
+                "rows_frac": rows_counted / sec / 1e9 / HBM_PEAK_GBS if sec > 0 else None,
+                "bytes_per_level_diagonal": rows_counted / ldiag if ldiag else None,
+                "wf_cells_per_s": cells_8d / sec if sec > 0 else None,
+                "level_diagonals_per_s": ldiag / sec if sec > 0 else None,
+                "orient_kernel_ms": o_ms, "orient_level_diagonals": ori_cells,
+                "unite": {"kernel": "sr_unite_kernel", "kernel_ms": u_ms, "united_bases": cnt["united_bases"],
+                          "bytes": cnt["united_bases"] * 24,
+                          "achieved": cnt["united_bases"] * 24 / (u_ms * 1e-3) / 1e9 if u_ms > 0 else None,
+                          "unit": "GB/s", "bound": "hbm (random access, atomics)",
+                          "frac": cnt["united_bases"] * 24 / (u_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if u_ms > 0 else None}}
+        # PMC passes cannot run inside this process: the recorded ones are attached only when they were taken for
+        # this kernel on this workload, and carry the kernel time and box they were measured at
+        ppath = os.path.join(ROOT, "profiles", "r03_counters.json")
+        if world == 1 and args.config == "C2" and args.nseq == 64 and os.path.exists(ppath):
             try:
                 pmc = json.load(open(ppath))
             except Exception:
                 pmc = {}
-        roof = {"bound": "hbm", "kernel": ctx.align_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc.get("align_hbm_bytes_per_launch"),
-                "kernel_ms": a_ms, "row_bytes_loaded_per_launch": cnt["row_bytes_loaded"],
-                "row_bytes_stored_per_launch": cnt["row_bytes_stored"], "wf_cells_per_launch": cells,
-                "bytes_per_cell": row_bytes / cells if cells else None,
-                "traffic_frac_of_peak": (pmc["align_hbm_bytes_per_launch"] / (pmc["align_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS)
-                if pmc.get("align_hbm_bytes_per_launch") and pmc.get("align_kernel_ms") else None,
-                "valu_issue_frac": pmc.get("align_valu_issue_frac"),
-                "pmc_source": "profiles/r02_counters.json" if pmc else None,
-                "unite_kernel_ms": u_ms, "orient_kernel_ms": o_ms, "orient_wf_cells_per_launch": ori_cells,
-                "wf_cells_per_s": cells / (a_ms * 1e-3) if a_ms > 0 else None}
-        if roof["valu_issue_frac"] and roof["valu_issue_frac"] > max(roof["frac"], roof["traffic_frac_of_peak"] or 0):
-            roof["bound"] = "valu"
+            if pmc.get("align_kernel") == ctx.align_kernel and pmc.get("align_hbm_bytes_per_launch"):
+                roof["traffic"] = pmc["align_hbm_bytes_per_launch"]
+                roof["traffic_source"] = {"file": "profiles/r03_counters.json", "recorded_kernel_ms": pmc.get("align_kernel_ms"),
+                                          "recorded_on": pmc.get("host"), "recorded_git": pmc.get("git"),
+                                          "traffic_over_rows_counted": pmc["align_hbm_bytes_per_launch"] / rows_counted if rows_counted else None,
+                                          "dram_bytes": pmc.get("align_dram_bytes_per_launch"),
+                                          "mall_hit_bytes": pmc.get("align_mall_hit_bytes_per_launch"),
+                                          "valu_issue_frac": pmc.get("align_valu_issue_frac"),
+                                          "wait_any_frac": pmc.get("align_wait_any_frac")}
         out = {
             "metric": metric, "value": total_pairs * args.steps / dt, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -287,6 +366,8 @@ def main():
         }
         if labels_sha:
             out["labels_sha256"] = labels_sha
+        if world == 1 and not args.no_host_stages:
+            out["host_stages_ms"] = host_stages(recs, ctx)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(recs, my_pairs, workload.split(":")[0])
             out["speedup_vs_cpu_best_leg"] = out["value"] / out["cpu_baseline"]["value"]
@@ -299,4 +380,14 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException:
+        # a rank that fails before a collective must not leave the others waiting in it until the RCCL timeout:
+        # report, then leave at once with a non-zero code -- torch.distributed.run ends the remaining ranks
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush(); sys.stdout.flush()
+        os._exit(1) if int(os.environ.get("WORLD_SIZE", "1")) > 1 else sys.exit(1)

@@ -296,7 +296,14 @@ static const char *next_field(const char *p, const char *end, const char **fs, s
     return p;
 }
 
-char *sro_compact_gfa(const char *gfa, uint64_t *n_nodes, uint64_t *n_edges) {
+/* Handle codec, src/bidirected_graph.rs:9-64: node id << 1 | reverse bit, Display "{id}{+|-}" */
+uint64_t sro_handle_new(uint64_t node_id, int is_reverse) { return (node_id << 1) | (is_reverse ? 1u : 0u); }
+uint64_t sro_handle_node_id(uint64_t h) { return H_ID(h); }
+int sro_handle_is_reverse(uint64_t h) { return (int)(h & 1); }
+char sro_handle_orientation_char(uint64_t h) { return (h & 1) ? '-' : '+'; }
+uint64_t sro_handle_flip(uint64_t h) { return H_FLIP(h); }
+
+static char *gfa_text_pass(const char *gfa, int do_compact, uint64_t *n_nodes, uint64_t *n_edges) {
     cgraph g; memset(&g, 0, sizeof(g));
     const char *p = gfa, *end = gfa + strlen(gfa);
     uint64_t pcap = 0;
@@ -341,8 +348,7 @@ char *sro_compact_gfa(const char *gfa, uint64_t *n_nodes, uint64_t *n_edges) {
         }
         p = le < end ? le + 1 : end;
     }
-    compact(&g);
-    renumber_nodes_sequentially(&g);
+    if (do_compact) { compact(&g); renumber_nodes_sequentially(&g); }
     /* write_gfa ops:880-925 */
     size_t cap = 1 << 16, len = 0;
     char *out = (char *)malloc(cap);
@@ -380,5 +386,51 @@ char *sro_compact_gfa(const char *gfa, uint64_t *n_nodes, uint64_t *n_edges) {
     free(g.nodes); free(g.edges);
     for (uint64_t pi = 0; pi < g.npaths; pi++) { free(g.paths[pi].name); free(g.paths[pi].steps); }
     free(g.paths);
+    return out;
+}
+
+char *sro_compact_gfa(const char *gfa, uint64_t *n_nodes, uint64_t *n_edges) { return gfa_text_pass(gfa, 1, n_nodes, n_edges); }
+/* the graph of a GFA text written back by write_gfa (ops:880-925) unchanged: the writer's line formats on their own */
+char *sro_rewrite_gfa(const char *gfa, uint64_t *n_nodes, uint64_t *n_edges) { return gfa_text_pass(gfa, 0, n_nodes, n_edges); }
+/* BiPath::get_sequence (src/bidirected_graph.rs:113-154): spell path `index` of a GFA text; malloc'd, NUL-terminated */
+char *sro_gfa_path_sequence(const char *gfa, uint64_t index) {
+    /* nodes by id from the S lines, then the steps of the index-th P line */
+    const char *p = gfa, *end = gfa + strlen(gfa);
+    uint64_t cap = 16, nn = 0, seen = 0;
+    struct nd { uint64_t id; const char *s; size_t n; } *nodes = malloc(sizeof(*nodes) * cap);
+    const char *steps = NULL; size_t steps_n = 0;
+    while (p < end) {
+        const char *le = memchr(p, '\n', (size_t)(end - p));
+        if (!le) le = end;
+        const char *f; size_t fl;
+        if (le > p + 1 && p[0] == 'S' && p[1] == '\t') {
+            const char *q = next_field(p + 2, le, &f, &fl);
+            if (nn == cap) { cap *= 2; nodes = realloc(nodes, sizeof(*nodes) * cap); }
+            nodes[nn].id = strtoull(f, NULL, 10);
+            next_field(q + 1, le, &f, &fl);
+            nodes[nn].s = f; nodes[nn].n = fl; nn++;
+        } else if (le > p + 1 && p[0] == 'P' && p[1] == '\t') {
+            if (seen++ == index) { const char *q = next_field(p + 2, le, &f, &fl); next_field(q + 1, le, &steps, &steps_n); }
+        }
+        p = le < end ? le + 1 : end;
+    }
+    size_t ocap = 64, on = 0;
+    char *out = malloc(ocap);
+    const char *s = steps, *se = steps ? steps + steps_n : NULL;
+    while (s && s < se) {
+        uint64_t id = 0;
+        while (s < se && *s >= '0' && *s <= '9') { id = id * 10 + (uint64_t)(*s - '0'); s++; }
+        const int r = (s < se && *s == '-');
+        if (s < se) s++;
+        if (s < se && *s == ',') s++;
+        for (uint64_t i = 0; i < nn; i++) if (nodes[i].id == id) {
+            while (on + nodes[i].n + 1 > ocap) { ocap *= 2; out = realloc(out, ocap); }
+            for (size_t k = 0; k < nodes[i].n; k++)
+                out[on++] = r ? (char)rc_node_base((uint8_t)nodes[i].s[nodes[i].n - 1 - k]) : nodes[i].s[k];
+            break;
+        }
+    }
+    out[on] = 0;
+    free(nodes);
     return out;
 }

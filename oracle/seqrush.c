@@ -85,6 +85,7 @@ int32_t sro_max_score_for_divergence(const sro_penalties *p, uint64_t seq_len,
 /* parse_sparsification seqrush.rs:356-431 */
 static int parse_f64(const char *s, double *out) {
     if (!*s) return -1;
+    for (const char *q = s; *q; q++) if (*q == 'x' || *q == 'X') return -1;   /* strtod takes hex floats, Rust's f64 parse does not */
     char *end;
     double v = strtod(s, &end);
     if (*end != 0 || isspace((unsigned char)s[0])) return -1;
@@ -92,13 +93,15 @@ static int parse_f64(const char *s, double *out) {
     return 0;
 }
 static int parse_usize(const char *s, size_t n, uint64_t *out) {
-    if (n == 0 || n > 19) return -1;
+    if (n == 0) return -1;
     uint64_t v = 0;
     size_t i = 0;
     if (s[0] == '+') { i = 1; if (n == 1) return -1; }
     for (; i < n; i++) {
         if (!isdigit((unsigned char)s[i])) return -1;
-        v = v * 10 + (uint64_t)(s[i] - '0');
+        const uint64_t d = (uint64_t)(s[i] - '0');
+        if (v > (UINT64_MAX - d) / 10) return -1;         /* usize overflow is an Err in Rust */
+        v = v * 10 + d;
     }
     *out = v;
     return 0;
@@ -482,6 +485,64 @@ int64_t sro_align_and_unite_list(sro_seqrush *s, const sro_params *p, const uint
         done++;
     }
     if (dp_cells) *dp_cells = cells;
+    return failed ? -1 : done;
+}
+
+/* the same, and the per-pair results kept for a full-size comparison (tests): score, strand, length and a 64-bit
+ * digest of the CIGAR runs (and their count) of every pair, in list order.  Test infrastructure like everything here. */
+/* digest of a raw CIGAR (bytes M X I D): its maximal runs as words (len << 4) | code, code M=0 X=1 D=2 I=3 (the
+ * device's op codes), summed as mix(word ^ index * golden) mod 2^64 -- order-sensitive and computable with array
+ * operations on the other side */
+static uint64_t dg_mix(uint64_t x) {
+    x += 0x9e3779b97f4a7c15ULL;
+    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    x = (x ^ (x >> 27)) * 0x94d049bb133111ebULL;
+    return x ^ (x >> 31);
+}
+static uint64_t cigar_run_digest(const uint8_t *b, int64_t n, uint32_t *nruns) {
+    uint64_t h = 0, idx = 0;
+    int64_t i = 0;
+    while (i < n) {
+        int64_t j = i;
+        while (j < n && b[j] == b[i]) j++;
+        const uint64_t code = b[i] == 'M' ? 0 : b[i] == 'X' ? 1 : b[i] == 'D' ? 2 : 3;
+        const uint64_t w = ((uint64_t)(j - i) << 4) | code;
+        h += dg_mix(w ^ (idx * 0x9e3779b97f4a7c15ULL));
+        idx++; i = j;
+    }
+    if (nruns) *nruns = (uint32_t)idx;
+    return h;
+}
+uint64_t sro_cigar_run_digest(const uint8_t *b, uint64_t n) { return cigar_run_digest(b, (int64_t)n, 0); }
+int64_t sro_align_and_unite_list_collect(sro_seqrush *s, const sro_params *p, const uint32_t *pq, const uint32_t *pt,
+                                         uint64_t count, int do_unite, int32_t *score, uint8_t *is_reverse,
+                                         uint32_t *cigar_len, uint64_t *cigar_digest) {
+    int64_t done = 0;
+    int failed = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(p->threads > 0 ? p->threads : 1) reduction(+:done)
+#endif
+    for (uint64_t idx = 0; idx < count; idx++) {
+        const uint32_t q = pq[idx], t = pt[idx];
+        sro_alignment a;
+        if (sro_align_pair(s, p, q, t, &a)) { failed = 1; continue; }
+        score[idx] = a.score; is_reverse[idx] = (uint8_t)(a.is_reverse != 0);
+        cigar_digest[idx] = cigar_run_digest(a.cigar_bytes, a.cigar_len, &cigar_len[idx]);
+        int keep = do_unite;
+        if (keep && p->max_divergence >= 0.0) {
+            uint64_t L = s->seqs[q].len < s->seqs[t].len ? s->seqs[q].len : s->seqs[t].len;
+            if (a.score > sro_max_score_for_divergence(&p->pen, L, p->max_divergence)) keep = 0;
+        }
+        if (keep) {
+            char *cig = sro_cigar_bytes_to_string(a.cigar_bytes, a.cigar_len);
+            int64_t r = sro_process_alignment(s, cig, q, t, p->min_match_len, a.is_reverse,
+                                              0, s->seqs[q].len, 0, s->seqs[t].len);
+            if (r < 0) failed = 1;
+            free(cig);
+        }
+        sro_alignment_free(&a);
+        done++;
+    }
     return failed ? -1 : done;
 }
 

@@ -192,6 +192,12 @@ int64_t sro_align_and_unite(sro_seqrush *s, const sro_params *p,
 /* the same over an explicit ordered pair list */
 int64_t sro_align_and_unite_list(sro_seqrush *s, const sro_params *p, const uint32_t *pq, const uint32_t *pt,
                                  uint64_t count, uint64_t *dp_cells);
+/* the same, keeping per-pair score / strand / number of CIGAR runs / run digest (full-size comparisons in tests/);
+ * do_unite = 0: align only */
+int64_t sro_align_and_unite_list_collect(sro_seqrush *s, const sro_params *p, const uint32_t *pq, const uint32_t *pt,
+                                         uint64_t count, int do_unite, int32_t *score, uint8_t *is_reverse,
+                                         uint32_t *cigar_runs, uint64_t *cigar_digest);
+uint64_t sro_cigar_run_digest(const uint8_t *raw_cigar, uint64_t n);
 /* sparsified ordered pair list (own definition, see seqrush.c; PARITY UNPINNED: allwave's rules are absent).
  * Arrays are malloc'd (free()). */
 int sro_sparsified_pairs(const sro_seqrush *s, const sro_sparsification *sp, uint64_t seed, int exclude_self,
@@ -209,7 +215,16 @@ char *sro_build_gfa(sro_seqrush *s, int canonical, int faithful_scan,
 /* compact() + renumber_nodes_sequentially() (src/bidirected_ops.rs:75-490) on a --no-compact GFA text as
  * sro_build_gfa writes it: the graph the reference writes for --no-sort without --no-compact
  * (src/bidirected_gfa_writer.rs:39-51).  Literal restatement, quadratic: test-sized graphs only.  malloc'd text. */
+/* Handle codec (src/bidirected_graph.rs:9-64) */
+uint64_t sro_handle_new(uint64_t node_id, int is_reverse);
+uint64_t sro_handle_node_id(uint64_t h);
+int sro_handle_is_reverse(uint64_t h);
+char sro_handle_orientation_char(uint64_t h);
+uint64_t sro_handle_flip(uint64_t h);
 char *sro_compact_gfa(const char *gfa, uint64_t *n_nodes, uint64_t *n_edges);
+/* parse + write_gfa (ops:880-925) without compaction; spell a path (bidirected_graph.rs:113-154) */
+char *sro_rewrite_gfa(const char *gfa, uint64_t *n_nodes, uint64_t *n_edges);
+char *sro_gfa_path_sequence(const char *gfa, uint64_t index);
 /* canonical min-Pos label per element of the UF (len = uf size) */
 void sro_canonical_labels(sro_seqrush *s, uint64_t *labels);
 

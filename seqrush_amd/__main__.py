@@ -51,8 +51,24 @@ def main(argv=None):
             run_seqrush(args)
     except (SeqRushError, ValueError) as e:
         print(f"Error: {e}", file=sys.stderr)
+        if ns.gpus > 1:
+            _leave_ranks()
         return 1
+    except BaseException:
+        if ns.gpus > 1:                 # any other failure of a rank: the same quick exit
+            import traceback
+            traceback.print_exc()
+            _leave_ranks()
+        raise
     return 0
+
+
+def _leave_ranks():
+    """A rank that failed (load error, device fault bits from ctx.sync()) leaves at once with a non-zero code instead of
+    finalising the interpreter with a live process group: the other ranks may already sit in the label all-gather or a
+    barrier, and torch.distributed.run ends them as soon as one worker has failed -- not after the RCCL timeout."""
+    sys.stderr.flush(); sys.stdout.flush()
+    os._exit(1)
 
 
 if __name__ == "__main__":

@@ -40,6 +40,16 @@ static bool load_sequences(const std::string &path, std::vector<Seq> &out) {
     return true;
 }
 
+// label part file of a shard run: header + uf_size canonical labels (u64).  The header lets the merge run refuse parts of
+// another input, another shard count, a duplicated part or an incomplete set.
+struct PartHeader { char magic[8]; uint64_t uf_size, shard_rank, shard_count, input_hash, flags; };
+static const char PART_MAGIC[8] = {'S', 'R', 'L', 'A', 'B', 'E', 'L', '1'};
+static uint64_t fnv1a(const void *data, size_t n, uint64_t h = 0xcbf29ce484222325ULL) {
+    const unsigned char *b = (const unsigned char *)data;
+    for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 0x100000001b3ULL; }
+    return h;
+}
+
 static void usage() {
     fprintf(stderr, "usage: seqrush_mi355x -s in.fa [-o output.gfa] [-k 0] [-S 0,5,8,2,24,1] [--orientation-scores 0,1,1,1]\n"
                     "       [-d max_divergence] [-x none|auto|random:F|connectivity:P|tree:kn[,kf[,rf[,k]]]] [-p in.paf] [--output-alignments out.paf] --no-sort [--no-compact] [--device N]\n"
@@ -86,6 +96,12 @@ int main(int argc, char **argv) {
         else { usage(); return 2; }
     }
     if (sequences.empty()) { usage(); return 2; }
+    if (shard_count > 1 && labels_out.empty()) {
+        fprintf(stderr, "Error: --shard %u/%u aligns a part of the pair list only: give --labels-out and merge the parts with --labels-in "
+                        "(a graph of one shard would be silently incomplete)\n", shard_rank, shard_count);
+        return 1;
+    }
+    if (!labels_in.empty() && (shard_count > 1 || !labels_out.empty())) { fprintf(stderr, "Error: --labels-in is the merge run: no --shard / --labels-out\n"); return 1; }
     if (aligner != "allwave" && aligner != "AllWave") { fprintf(stderr, "Error: aligner '%s' is out of scope; only 'allwave'\n", aligner.c_str()); return 1; }
     if (!no_sort) { fprintf(stderr, "Error: only --no-sort output is implemented (the Ygs layout is outside the hot path); compaction runs unless --no-compact\n"); return 1; }
     std::vector<Seq> seqs;
@@ -105,6 +121,13 @@ int main(int argc, char **argv) {
     }
     p.min_match_len = (uint64_t)k; p.max_divergence = max_div; p.device = device; p.canonical_labels = 1;
     p.shard_rank = shard_rank; p.shard_count = shard_count;
+    // what a part file must agree on: the sequences (bytes and boundaries) and everything that decides pairs and unions
+    uint64_t input_hash = fnv1a(bases.data(), bases.size());
+    input_hash = fnv1a(offsets.data(), offsets.size() * 8, input_hash);
+    {
+        const std::string cfg = scores + "|" + ori + "|" + sparsify + "|" + std::to_string(k) + "|" + std::to_string(max_div);
+        input_hash = fnv1a(cfg.data(), cfg.size(), input_hash);
+    }
     printf("Building graph with %zu sequences (total length: %zu)\n", seqs.size(), bases.size());
     printf("Total sequence pairs: %zu (sparsification: %s)\n", seqs.size() * seqs.size(), sparsify.c_str());
     // one resident context: load (or PAF replay) -> align -> unite -> graph induction, all on the device
@@ -115,12 +138,25 @@ int main(int argc, char **argv) {
         if (sr_ctx_load_pairs(ctx, &set, &p, nullptr, nullptr, 0)) return die();
         const uint64_t ufn = sr_ctx_uf_size(ctx);
         std::vector<uint64_t> lab(ufn);
+        std::vector<char> seen;
+        uint64_t parts_of = 0;
         for (const std::string &path : labels_in) {
             FILE *f = fopen(path.c_str(), "rb");
-            if (!f || fread(lab.data(), 8, ufn, f) != ufn) { fprintf(stderr, "Error: cannot read %llu labels from %s\n", (unsigned long long)ufn, path.c_str()); if (f) fclose(f); sr_ctx_destroy(ctx); return 1; }
-            fclose(f);
+            PartHeader h;
+            auto bad = [&](const char *why) { fprintf(stderr, "Error: label part %s: %s\n", path.c_str(), why); if (f) fclose(f); sr_ctx_destroy(ctx); return 1; };
+            if (!f || fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, PART_MAGIC, 8) != 0) return bad("not a label part file (no header)");
+            if (h.uf_size != ufn || h.input_hash != input_hash) return bad("written for other sequences or other options (-S / --orientation-scores / -x / -k / -d)");
+            if (h.shard_count == 0 || h.shard_rank >= h.shard_count) return bad("bad shard in header");
+            if (parts_of == 0) { parts_of = h.shard_count; seen.assign(parts_of, 0); }
+            if (h.shard_count != parts_of) return bad("belongs to a run with another shard count");
+            if (seen[h.shard_rank]) return bad("shard given twice");
+            seen[h.shard_rank] = 1;
+            if (fread(lab.data(), 8, ufn, f) != ufn || fgetc(f) != EOF) return bad("truncated or oversized");
+            fclose(f); f = nullptr;
             if (sr_ctx_merge_labels_host(ctx, lab.data(), 1)) return die();
         }
+        for (uint64_t r = 0; r < parts_of; r++)
+            if (!seen[r]) { fprintf(stderr, "Error: shard %llu/%llu is missing from the --labels-in set\n", (unsigned long long)r, (unsigned long long)parts_of); sr_ctx_destroy(ctx); return 1; }
     } else if (!paf_in.empty()) {                            // align_and_unite_from_paf (src/seqrush.rs:510-609)
         printf("Reading alignments from PAF file: %s\n", paf_in.c_str());
         if (sr_ctx_load_paf(ctx, &set, &p, paf_in.c_str())) return die();
@@ -143,7 +179,9 @@ int main(int argc, char **argv) {
         std::vector<uint64_t> lab(ufn);
         if (sr_ctx_download_labels(ctx, lab.data())) return die();
         FILE *f = fopen(labels_out.c_str(), "wb");
-        if (!f || fwrite(lab.data(), 8, ufn, f) != ufn) { fprintf(stderr, "Error: cannot write %s\n", labels_out.c_str()); if (f) fclose(f); sr_ctx_destroy(ctx); return 1; }
+        PartHeader h;
+        memcpy(h.magic, PART_MAGIC, 8); h.uf_size = ufn; h.shard_rank = shard_rank; h.shard_count = shard_count; h.input_hash = input_hash; h.flags = 0;
+        if (!f || fwrite(&h, sizeof(h), 1, f) != 1 || fwrite(lab.data(), 8, ufn, f) != ufn) { fprintf(stderr, "Error: cannot write %s\n", labels_out.c_str()); if (f) fclose(f); sr_ctx_destroy(ctx); return 1; }
         fclose(f);
         printf("Labels of shard %u/%u written to %s\n", shard_rank, shard_count, labels_out.c_str());
         sr_ctx_destroy(ctx);

@@ -104,6 +104,7 @@ extern "C" int sr_parse_orientation_scores(const char *s, sr_params *p) {   // :
 
 static bool parse_f64(const std::string &s, double *out) {
     if (s.empty() || isspace((unsigned char)s[0])) return false;
+    for (char ch : s) if (ch == 'x' || ch == 'X') return false;     // strtod takes hex floats, Rust's f64::from_str does not
     char *end;
     double v = strtod(s.c_str(), &end);
     if (*end != 0) return false;
@@ -132,9 +133,14 @@ extern "C" int sr_parse_sparsification(const char *cs, sr_params *p) {      // :
             return fail(SR_ERR_INVALID, "Tree sampling requires 1-4 values: tree:neighbor[,stranger[,random[,k-mer]]], got " + s);
         auto parse_usize = [](const std::string &t, uint64_t *v) {      // Rust str::parse::<usize>
             size_t i = (!t.empty() && t[0] == '+') ? 1 : 0;
-            if (i >= t.size() || t.size() > 19) return false;
+            if (i >= t.size()) return false;
             *v = 0;
-            for (; i < t.size(); i++) { if (t[i] < '0' || t[i] > '9') return false; *v = *v * 10 + (uint64_t)(t[i] - '0'); }
+            for (; i < t.size(); i++) {
+                if (t[i] < '0' || t[i] > '9') return false;
+                const uint64_t dgt = (uint64_t)(t[i] - '0');
+                if (*v > (0xffffffffffffffffULL - dgt) / 10) return false;      // overflow of a 64-bit usize: Err like Rust
+                *v = *v * 10 + dgt;
+            }
             return true;
         };
         uint64_t kn = 0, kf = 0, km = 16;
@@ -224,6 +230,7 @@ static void free_dev(sr_ctx *c) {
     c->d_nodes = c->d_minarr = c->d_labels = c->d_counters = nullptr;
     c->d_error = nullptr; c->d_queue = nullptr; c->d_oqueue = nullptr; c->d_order = nullptr; c->d_cbase = nullptr;
     c->d_bases = nullptr; c->d_max_score = nullptr; c->onwg = 0;
+    c->d_okeys = c->d_okeys2 = nullptr; c->d_ovals = nullptr; c->d_otemp = nullptr; c->otemp_bytes = 0;
     c->loaded = false; c->from_paf = false; c->aligned_batch_valid = false;
     for (int k = 0; k < 5; k++) c->ev_used[k] = 0;
 }
@@ -690,8 +697,10 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
     if (pq.empty()) { pq.push_back(0); pt.push_back(0); }
     DEV_UPLOAD(d_pq, uint32_t, pq);
     DEV_UPLOAD(d_pt, uint32_t, pt);
+    // (cb and order live until the stream synchronisation below: the uploads are asynchronous)
+    std::vector<uint64_t> cb((size_t)np + nbatch, 0);
+    std::vector<uint32_t> order(std::max<uint32_t>(np, 1), 0);
     {   // per-batch relative CIGAR bases: batch b owns entries [first_b + b, first_b + b + count_b]
-        std::vector<uint64_t> cb((size_t)np + nbatch, 0);
         for (uint32_t b = 0; b < nbatch; b++) {
             const uint32_t f = c->batch_first[b], l = c->batch_first[b + 1];
             for (uint32_t i = f; i <= l; i++) cb[(size_t)i + b] = c->cigar_base[i] - c->cigar_base[f];
@@ -699,7 +708,6 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
         DEV_UPLOAD(c->d_cbase, uint64_t, cb);
     }
     {   // cost-sorted dequeue order inside each batch: the longest pairs start first (self pairs last)
-        std::vector<uint32_t> order(std::max<uint32_t>(np, 1), 0);
         for (uint32_t b = 0; b < nbatch; b++) {
             const uint32_t f = c->batch_first[b], l = c->batch_first[b + 1];
             std::vector<uint32_t> idx(l - f);
@@ -712,7 +720,7 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
         DEV_UPLOAD(c->d_order, uint32_t, order);
     }
     DEV_UPLOAD(c->d_max_score, int32_t, max_score);
-    HIPCHK(hipStreamSynchronize(c->stream));   // host vectors go out of scope
+    HIPCHK(hipStreamSynchronize(c->stream));   // the uploads above have read their host vectors
     if ((r = dev_alloc(c, &d, sizeof(uint32_t)))) return r; c->d_queue = (uint32_t *)d;
     uint64_t oring_bytes = 0;
     if (impl) {
@@ -792,13 +800,14 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
     u.min_match_len = p->min_match_len; u.nodes = c->d_nodes; u.uf_size = c->uf_size;
     u.counters = c->d_counters; u.error_flag = c->d_error;
     {
-        char buf[640];
+        char buf[800];
         snprintf(buf, sizeof(buf),
-                 "{\"pairs\": %u, \"batches\": %u, \"symbol_bits\": %d, \"offset_bytes\": %zu, \"ring_cell_bytes\": %zu, \"kernel_impl\": %d, \"workgroups\": %d, "
+                 "{\"pairs\": %u, \"batches\": %u, \"symbol_bits\": %d, \"offset_bytes\": %zu, \"ring_cell_bytes\": %zu, \"kernel_impl\": %d, "
+                 "\"block_levels\": %d, \"two_piece\": %d, \"lazy_id_rows\": %d, \"workgroups\": %d, "
                  "\"threads_per_workgroup\": %d, \"workgroups_per_cu\": %d, \"lds_dynamic_bytes\": %zu, \"ring_bytes_per_workgroup\": %llu, "
                  "\"base_history_bytes_per_workgroup\": %llu, \"workspace_bytes\": %llu, \"cigar_arena_bytes\": %llu, "
                  "\"orientation_ring_bytes\": %llu, \"union_find_bytes\": %llu, \"device_free_bytes_at_load\": %zu}",
-                 np, nbatch, sm.bits, osz, impl == 2 ? rsz : osz, impl, nwg, c->nthreads, wg_per_cu, c->lds_bytes,
+                 np, nbatch, sm.bits, osz, impl == 2 ? rsz : osz, impl, impl == 2 ? kblock : 1, pen.two ? 1 : 0, lazy_id, nwg, c->nthreads, wg_per_cu, c->lds_bytes,
                  (unsigned long long)(impl ? bring_wg * rsz : ring_wg * osz), (unsigned long long)((impl ? bhist_wg : hist_wg) * osz),
                  (unsigned long long)((uint64_t)nwg * per_wg_bytes), (unsigned long long)(arena_ops * 4), (unsigned long long)oring_bytes,
                  (unsigned long long)(3ULL * c->uf_size * 8), free_b);

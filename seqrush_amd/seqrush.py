@@ -499,6 +499,8 @@ def run_seqrush_rank(args: Args):
     if rank == 0:
         print(f"Loaded {len(sequences)} sequences")
         print(f"Building graph with {len(sequences)} sequences (total length: {sum(len(s.data) for s in sequences)})")
+    if os.environ.get("SR_TEST_FAIL_RANK") == str(rank):       # test hook: a rank that fails before the collective
+        raise SeqRushError(-1, f"SR_TEST_FAIL_RANK: rank {rank} fails on purpose")
     sr = SeqRush(sequences, device=dev)
     ctx = sr.ctx
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)

@@ -14,7 +14,8 @@ _M1 = np.uint64(0xBF58476D1CE4E5B9)
 _M2 = np.uint64(0x94D049BB133111EB)
 _G = np.uint64(0x9E3779B97F4A7C15)
 _ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
-_COMP = {65: 84, 84: 65, 67: 71, 71: 67}
+# the reference's complement (src/bidirected_graph.rs:73-85): ACGT in either case -> upper-case complement, N/n -> N, other bytes unchanged
+_COMP = {**{b: b for b in range(256)}, 65: 84, 97: 84, 84: 65, 116: 65, 67: 71, 99: 71, 71: 67, 103: 67, 78: 78, 110: 78}
 
 
 def _r(seed: int, idx: np.ndarray) -> np.ndarray:

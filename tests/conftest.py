@@ -37,6 +37,18 @@ def gpu():
     return True
 
 
+def usable_cpus():
+    """CPUs this process may really use: affinity mask capped by the cgroup quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def canon_gfa(text):
     """H/S/P lines in order + L lines as a sorted multiset (the reference writes L lines
     in randomized HashSet order, src/bidirected_ops.rs:11, 898-907)."""

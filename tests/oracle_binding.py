@@ -129,11 +129,24 @@ def lib():
     L.sro_align_and_unite_list.restype = C.c_int64
     L.sro_align_and_unite_list.argtypes = [C.POINTER(SeqRushS), C.POINTER(Params), C.POINTER(C.c_uint32),
                                            C.POINTER(C.c_uint32), u64, C.POINTER(u64)]
+    L.sro_align_and_unite_list_collect.restype = C.c_int64
+    L.sro_align_and_unite_list_collect.argtypes = [C.POINTER(SeqRushS), C.POINTER(Params), C.POINTER(C.c_uint32),
+                                                   C.POINTER(C.c_uint32), u64, i32, C.POINTER(C.c_int32),
+                                                   C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(u64)]
+    L.sro_cigar_run_digest.restype = u64; L.sro_cigar_run_digest.argtypes = [C.c_char_p, u64]
     L.sro_sparsified_pairs.argtypes = [C.POINTER(SeqRushS), C.POINTER(Sparsification), u64, i32,
                                        C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(C.c_uint32)),
                                        C.POINTER(u64)]
     L.sro_compact_gfa.restype = vp
     L.sro_compact_gfa.argtypes = [C.c_char_p, C.POINTER(u64), C.POINTER(u64)]
+    L.sro_rewrite_gfa.restype = vp
+    L.sro_rewrite_gfa.argtypes = [C.c_char_p, C.POINTER(u64), C.POINTER(u64)]
+    L.sro_gfa_path_sequence.restype = vp; L.sro_gfa_path_sequence.argtypes = [C.c_char_p, u64]
+    L.sro_handle_new.restype = u64; L.sro_handle_new.argtypes = [u64, i32]
+    L.sro_handle_node_id.restype = u64; L.sro_handle_node_id.argtypes = [u64]
+    L.sro_handle_is_reverse.argtypes = [u64]
+    L.sro_handle_orientation_char.restype = C.c_char; L.sro_handle_orientation_char.argtypes = [u64]
+    L.sro_handle_flip.restype = u64; L.sro_handle_flip.argtypes = [u64]
     L.sro_build_gfa.restype = vp
     L.sro_build_gfa.argtypes = [C.POINTER(SeqRushS), i32, i32, C.POINTER(u64), C.POINTER(u64)]
     L.sro_canonical_labels.argtypes = [C.POINTER(SeqRushS), C.POINTER(u64)]
@@ -184,6 +197,34 @@ def cigar_bytes_to_string(cig: bytes) -> str:
     return s
 
 
+def cigar_run_digest(raw: bytes) -> int:
+    return lib().sro_cigar_run_digest(raw, len(raw))
+
+
+def cigar_run_digests(cigar_ops, cigar_off):
+    """the oracle's run digest (oracle/seqrush.c cigar_run_digest) of every alignment of a device result, from its
+    run-length op buffer (u32 (len << 4) | code, code 0 '=' 1 X 2 raw-D 3 raw-I) -- array operations only"""
+    import numpy as np
+    ops = np.asarray(cigar_ops, dtype=np.uint64)
+    off = np.asarray(cigar_off, dtype=np.int64)
+    n = len(off) - 1
+    cnt = np.diff(off)
+    idx = np.arange(len(ops), dtype=np.int64) - np.repeat(off[:-1], cnt)
+    G = np.uint64(0x9e3779b97f4a7c15)
+    with np.errstate(over="ignore"):
+        x = ops ^ (idx.astype(np.uint64) * G)
+        x = x + G
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xbf58476d1ce4e5b9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94d049bb133111eb)
+        x = x ^ (x >> np.uint64(31))
+        out = np.zeros(n, dtype=np.uint64)
+        nz = cnt > 0
+        if len(ops):
+            sums = np.add.reduceat(x, off[:-1][nz])
+            out[nz] = sums
+    return out
+
+
 def compact_gfa(gfa_text: str):
     """compact() + renumber of the reference (src/bidirected_ops.rs:75-490) on a --no-compact GFA -> (text, nodes, edges)"""
     L = lib()
@@ -192,6 +233,24 @@ def compact_gfa(gfa_text: str):
     s = C.cast(p, C.c_char_p).value.decode()
     L._libc.free(p)
     return s, nn.value, ne.value
+
+
+def rewrite_gfa(gfa_text: str):
+    """parse + write_gfa (src/bidirected_ops.rs:880-925), no compaction -> (text, nodes, edges)"""
+    L = lib()
+    nn = C.c_uint64(); ne = C.c_uint64()
+    p = L.sro_rewrite_gfa(gfa_text.encode(), C.byref(nn), C.byref(ne))
+    s = C.cast(p, C.c_char_p).value.decode()
+    L._libc.free(p)
+    return s, nn.value, ne.value
+
+
+def gfa_path_sequence(gfa_text: str, index: int) -> str:
+    L = lib()
+    p = L.sro_gfa_path_sequence(gfa_text.encode(), index)
+    s = C.cast(p, C.c_char_p).value.decode()
+    L._libc.free(p)
+    return s
 
 
 def parse_scores(s: str):
@@ -273,6 +332,23 @@ class OracleSeqRush:
         if r < 0:
             raise RuntimeError("sro_align_and_unite_list failed")
         return r, cells.value
+
+    def align_list_collect(self, params: Params, pairs, unite=True):
+        """align (and unite) an ordered pair list on params.threads threads -> per-pair (score, is_reverse, number of
+        CIGAR runs, run digest) arrays: what a full-size comparison with the device needs (see cigar_run_digests)"""
+        import numpy as np
+        n = len(pairs)
+        q = np.ascontiguousarray([a for a, _ in pairs], dtype=np.uint32)
+        t = np.ascontiguousarray([b for _, b in pairs], dtype=np.uint32)
+        sc = np.zeros(max(n, 1), dtype=np.int32); rv = np.zeros(max(n, 1), dtype=np.uint8)
+        nr = np.zeros(max(n, 1), dtype=np.uint32); dg = np.zeros(max(n, 1), dtype=np.uint64)
+        r = self.L.sro_align_and_unite_list_collect(
+            self.ptr, C.byref(params), q.ctypes.data_as(C.POINTER(C.c_uint32)), t.ctypes.data_as(C.POINTER(C.c_uint32)),
+            n, int(unite), sc.ctypes.data_as(C.POINTER(C.c_int32)), rv.ctypes.data_as(C.POINTER(C.c_uint8)),
+            nr.ctypes.data_as(C.POINTER(C.c_uint32)), dg.ctypes.data_as(C.POINTER(C.c_uint64)))
+        if r != n:
+            raise RuntimeError("sro_align_and_unite_list_collect failed")
+        return sc[:n], rv[:n], nr[:n], dg[:n]
 
     def sparsified_pairs(self, spec: str, seed=42, exclude_self=False):
         """ordered pair list of `-x spec` (own definition, unpinned: allwave's rules are not in the reference tree)"""

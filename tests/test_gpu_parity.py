@@ -12,7 +12,7 @@ import oracle_binding as ob
 import seqrush_amd as sa
 from seqrush_amd import synth, _lib
 from seqrush_amd.seqrush import SeqSet, Params, Context, build_gfa
-from conftest import canon_gfa
+from conftest import canon_gfa, usable_cpus
 
 pytestmark = pytest.mark.gpu
 
@@ -402,6 +402,43 @@ def test_label_merge_on_device(gpu):
         c.close()
 
 
+def _full_size_vs_oracle(recs, pairs, al, labels, ss, check_gfa=True):
+    """every pair of a full-size run against the oracle on all usable host CPUs: score, strand, number of CIGAR runs and
+    the run digest of every alignment (oracle/seqrush.c cigar_run_digest: equal iff the run-length CIGARs are equal, up to
+    64-bit hash collisions), the union-find partition and the canonical GFA"""
+    o = ob.OracleSeqRush(records=recs)
+    op = ob.default_params(); op.threads = usable_cpus()
+    sc, rv, nr, dg = o.align_list_collect(op, pairs, unite=True)
+    assert [(int(a), int(b)) for a, b in zip(al.query_idx, al.target_idx)] == list(pairs)
+    assert np.array_equal(al.score, sc), f"scores differ on {int((al.score != sc).sum())} pairs"
+    assert np.array_equal(al.is_reverse, rv)
+    assert np.array_equal(np.diff(al.cigar_off.astype(np.int64)), nr.astype(np.int64))
+    got = ob.cigar_run_digests(al.cigar_ops, al.cigar_off)
+    bad = np.nonzero(got != dg)[0]
+    assert len(bad) == 0, f"CIGARs differ on {len(bad)} pairs, first {pairs[int(bad[0])]}"
+    # the digest is the oracle's function of the raw bytes: spot-check it against bytes on a few pairs
+    for i in range(0, al.n, max(1, al.n // 16)):
+        raw = al.raw_cigar_bytes(i)
+        assert ob.cigar_run_digest(raw) == int(dg[i])
+        assert raw == o.align_pair(op, *pairs[i])["cigar"]
+    assert np.array_equal(o.canonical_labels(), labels), "UF partition differs"
+    if check_gfa:
+        g_gpu = build_gfa(ss, labels)
+        g_cpu = o.gfa(canonical=True)
+        assert canon_gfa(g_gpu[0]) == canon_gfa(g_cpu[0]) and g_gpu[1:] == g_cpu[1:]
+    o.close()
+
+
+def test_full_size_c2_parity_all_4096_pairs(gpu):
+    """BASELINE.json configs[1] "64 synthetic 5 kb sequences ..., GFA bit-match vs CPU" at its own size: all 4 096 CIGARs,
+    strands, scores, the partition and the canonical GFA equal the oracle's (src/seqrush.rs:728-756 over the whole list)"""
+    recs = synth.config_c2(64)
+    ss, al, labels, nodes, cnt = run_gpu(recs)
+    assert al.n == 4096
+    pairs = [(q, t) for q in range(64) for t in range(64)]
+    _full_size_vs_oracle(recs, pairs, al, labels, ss)
+
+
 def test_full_size_c2_properties(gpu):
     """BASELINE.json configs[1] at full size (4096 pairs) through size-independent properties:
     every CIGAR spells both sequences and costs its reported score; reverse pairs mirror scores;
@@ -637,10 +674,9 @@ def test_multi_rank_bench_matches_single_rank(gpu):
     assert one.returncode == 0, one.stderr[-2000:]
     d1 = json.loads(one.stdout.strip().split("\n")[-1])
     env["SR_BENCH_SINGLE_DEVICE"] = "1"
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
-                          "--gpus", "2", "--nseq", "8", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
-                         capture_output=True, text=True, timeout=600, env=env)
+    # started plainly, the way the driver starts `--gpus 1`: bench.py launches its own ranks as a child process
+    two = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--nseq", "8", "--steps", "1",
+                          "--warmup", "0", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
     assert two.returncode == 0, two.stderr[-2000:]
     d2 = json.loads(two.stdout.strip().split("\n")[-1])
     assert d2["n_gpus"] == 2 and d2["config"]["pairs_per_gpu"] == 32
@@ -904,6 +940,17 @@ def test_full_size_c4_properties(gpu):
                            for s in f[2].split(",")) == names[f[1]].decode()
 
 
+def test_full_size_c4_parity_all_pairs(gpu):
+    """BASELINE.json configs[3] at full size against the oracle: all 116 202 pairs of the tree:3,3,0.1 list -- scores,
+    strands, CIGAR run digests -- and the union-find partition (label equality)"""
+    recs = synth.config_c4()
+    ss = SeqSet(recs); ctx = Context(0); ctx.load(ss, Params(sparsification="tree:3,3,0.1"))
+    pairs = ctx.pairs()
+    al = ctx.align_all(unite=True); ctx.sync(); labels = ctx.download_labels(); ctx.close()
+    assert al.n == len(pairs) > 100000
+    _full_size_vs_oracle(recs, pairs, al, labels, ss, check_gfa=False)
+
+
 def test_full_size_c5_properties(gpu):
     """BASELINE.json configs[4] at full size on one GPU: 256 x 50 kb with inversions, 65 536 ordered pairs, int32 rows.
     Size-independent properties: every score >= 0 and symmetric, self pairs 0, strands symmetric and exactly the
@@ -996,3 +1043,36 @@ def test_multi_gpu_cli_hosts(gpu, tmp_path):
     out3 = tmp_path / "frompaf.gfa"
     r = subprocess.run([exe, "-s", str(fa), "-o", str(out3), "--no-sort", "-p", str(paf)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and canon_gfa(out3.read_text()) == want
+    # a shard without --labels-out would write the graph of a part of the pair list: refused
+    r = subprocess.run([exe, "-s", str(fa), "-o", str(tmp_path / "x.gfa"), "--no-sort", "--shard", "0/3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "--labels-out" in r.stderr and not (tmp_path / "x.gfa").exists()
+    # the merge run checks the part headers: incomplete set, duplicated part, parts of another run, headerless dump
+    def merge(ps, extra=()):
+        c = [exe, "-s", str(fa), "-o", str(tmp_path / "y.gfa"), "--no-sort"] + list(extra)
+        for p_ in ps:
+            c += ["--labels-in", p_]
+        return subprocess.run(c, capture_output=True, text=True, timeout=300)
+    r = merge(parts[:2]); assert r.returncode != 0 and "missing" in r.stderr
+    r = merge([parts[0], parts[0], parts[1]]); assert r.returncode != 0 and "twice" in r.stderr
+    r = merge(parts, extra=("-k", "5")); assert r.returncode != 0 and "other options" in r.stderr
+    raw = tmp_path / "raw.bin"; raw.write_bytes(open(parts[0], "rb").read()[48:])
+    r = merge([str(raw), parts[1], parts[2]]); assert r.returncode != 0 and "header" in r.stderr
+
+
+def test_failing_rank_ends_the_job_quickly(gpu, tmp_path):
+    """a rank that fails before the label all-gather must not leave the others waiting for the collective's
+    timeout.  SR_TEST_FAIL_RANK makes rank 1 raise after the process group exists; the launcher returns non-zero in
+    seconds."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    recs = synth.snp_family(4, 300, 0.05, 712)
+    fa = tmp_path / "in.fa"
+    fa.write_bytes(b"".join(b">" + n.encode() + b"\n" + s + b"\n" for n, s in recs))
+    env = dict(os.environ, SR_BENCH_SINGLE_DEVICE="1", PYTHONPATH=root, MASTER_PORT="29613", SR_TEST_FAIL_RANK="1")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-m", "seqrush_amd", "-s", str(fa), "-o", str(tmp_path / "o.gfa"), "--no-sort", "--gpus", "2"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode != 0 and "SR_TEST_FAIL_RANK" in r.stderr
+    assert time.time() - t0 < 120 and not (tmp_path / "o.gfa").exists()

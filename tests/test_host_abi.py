@@ -59,7 +59,10 @@ def test_parsers_match_oracle():
         if r == 0:
             assert (p.c.match_score, p.c.mismatch_penalty, p.c.gap_open1, p.c.gap_ext1) == (po.match, po.mismatch, po.gap_open1, po.gap_ext1)
             assert (p.c.gap_open2 >= 0) == (po.gap_open2 >= 0)
-    for s in ["none", "1.0", "auto", "random:0.5", "random:0", "connectivity:0.3", "tree:3,3,0.1", "tree:", "0.5", "x"]:
+    for s in ["none", "1.0", "auto", "random:0.5", "random:0", "connectivity:0.3", "tree:3,3,0.1", "tree:", "0.5", "x",
+              # Rust's parsers (src/seqrush.rs:356-431): hex floats are errors, a 20-digit usize is fine, 2^64 overflows
+              "0x.8", "random:0x1p-1", "tree:3,3,0X.1", "tree:18446744073709551615", "tree:18446744073709551616",
+              "tree:+3,+2", "tree:3,3,0.1,99999999999999999999"]:
         sp = ob.Sparsification()
         r = ob.lib().sro_parse_sparsification(s.encode(), C.byref(sp))
         p = Params()
@@ -67,6 +70,8 @@ def test_parsers_match_oracle():
         assert (rc == 0) == (r == 0), s
         if r == 0:
             assert p.c.sparsify_kind == sp.kind
+        assert (r == 0) == (s in ("none", "1.0", "auto", "random:0.5", "connectivity:0.3", "tree:3,3,0.1", "0.5",
+                                  "tree:18446744073709551615", "tree:+3,+2")), s
     assert sa.AlignmentScores.parse("0,5,8,2,24,1").gap2_extend == 1
     assert sa.AlignmentScores.parse_orientation("0,1,1,1").gap1_open == 1
     with pytest.raises(sa.SeqRushError):
