@@ -56,6 +56,8 @@ typedef struct {
     int score;      /* score held by this slot, -1 = none */
     int lo, hi;     /* lo > hi : empty level */
     int off0;       /* index = k + off0 */
+    int wlo, whi;   /* modular rows: diagonals written by the level the slot held last */
+    int ilo, ihi;   /* modular rows: diagonals initialised so far; inside, everything outside [wlo, whi] is WF_NULL */
     int32_t *c[5];
 } level_t;
 
@@ -67,6 +69,8 @@ typedef struct {
     level_t *lv;
     int nlv;        /* modular: scope ; full: allocated count */
     int cap, shift; /* modular storage */
+    int32_t *nullrow; /* modular: a row of WF_NULL standing in for absent source levels */
+    int null_ilo, null_ihi;
     uint64_t cells;
 } wfa_t;
 
@@ -130,9 +134,13 @@ static void wfa_init(wfa_t *a, const view_t *w, const sro_penalties *pen,
             a->lv[i].score = -1;
             a->lv[i].lo = 1; a->lv[i].hi = 0;
             a->lv[i].off0 = a->shift;
+            a->lv[i].wlo = 1; a->lv[i].whi = 0; a->lv[i].ilo = 1; a->lv[i].ihi = 0;
             for (int j = 0; j < 5; j++)
                 a->lv[i].c[j] = (int32_t *)arena_alloc(sizeof(int32_t) * (size_t)a->cap);
         }
+        /* (rows are initialised to WF_NULL window by window as the wavefront widens: row_cover) */
+        a->nullrow = (int32_t *)arena_alloc(sizeof(int32_t) * (size_t)a->cap);
+        a->null_ilo = 1; a->null_ihi = 0;
     } else {
         a->nlv = 0;
         a->lv = NULL;
@@ -224,6 +232,7 @@ static inline int32_t wf_extend(const view_t *w, int k, int32_t off) {
 static void wfa_level0(wfa_t *a, int begin) {
     level_t *L = wfa_slot(a, 0);
     lv_prepare(a, L, 0, 0, 0);
+    if (a->modular) { L->wlo = 0; L->whi = 0; L->ilo = 0; L->ihi = 0; }
     for (int j = 0; j < 5; j++) L->c[j][0 + L->off0] = WF_NULL;
     int32_t off = 0;
     if (begin == SRO_M) off = wf_extend(&a->w, 0, 0);
@@ -231,9 +240,124 @@ static void wfa_level0(wfa_t *a, int begin) {
     a->cells += 1;
 }
 
+/* make the rows of a modular slot (L != NULL) or the NULL row readable over diagonals [lo, hi]: what has never been
+ * initialised becomes WF_NULL (windows only grow, a few cells per level) */
+static void row_cover(wfa_t *a, level_t *L, int lo, int hi) {
+    const int sh = a->shift;
+    int *ilo = L ? &L->ilo : &a->null_ilo, *ihi = L ? &L->ihi : &a->null_ihi;
+    const int nrows = L ? 5 : 1;
+    if (*ilo > *ihi) {
+        for (int j = 0; j < nrows; j++) { int32_t *r = (L ? L->c[j] : a->nullrow) + sh; for (int k = lo; k <= hi; k++) r[k] = WF_NULL; }
+        *ilo = lo; *ihi = hi;
+        return;
+    }
+    for (int j = 0; j < nrows; j++) {
+        int32_t *r = (L ? L->c[j] : a->nullrow) + sh;
+        for (int k = lo; k < *ilo; k++) r[k] = WF_NULL;
+        for (int k = *ihi + 1; k <= hi; k++) r[k] = WF_NULL;
+    }
+    if (lo < *ilo) *ilo = lo;
+    if (hi > *ihi) *ihi = hi;
+}
+
+/* recurrences of one level over [lo, hi]: distinct rows in, distinct rows out (restrict parameters: what lets the
+ * compiler vectorise without alias checks) */
+static void __attribute__((noinline)) step_kernel(int lo, int hi, int plen, int tlen, int two,
+        const int32_t *restrict mx, const int32_t *restrict mo1, const int32_t *restrict si1, const int32_t *restrict sd1,
+        const int32_t *restrict mo2, const int32_t *restrict si2, const int32_t *restrict sd2,
+        int32_t *restrict oM, int32_t *restrict oI1, int32_t *restrict oI2, int32_t *restrict oD1, int32_t *restrict oD2) {
+    const int32_t nul2 = two ? INT32_MAX : -1;               /* one-piece: every I2 / D2 cell fails "<= limit" */
+    for (int k = lo; k <= hi; k++) {
+        const int32_t limv = IMIN(tlen, plen + k);           /* >= 0 on [-plen, tlen] */
+        const int32_t lim2 = IMIN(limv, nul2);
+        int32_t i1 = IMAX(mo1[k - 1], si1[k - 1]) + 1;
+        int32_t d1 = IMAX(mo1[k + 1], sd1[k + 1]);
+        int32_t i2 = IMAX(mo2[k - 1], si2[k - 1]) + 1;
+        int32_t d2 = IMAX(mo2[k + 1], sd2[k + 1]);
+        int32_t m = mx[k] + 1;
+        i1 = ((uint32_t)i1 > (uint32_t)limv) ? WF_NULL : i1;
+        d1 = ((uint32_t)d1 > (uint32_t)limv) ? WF_NULL : d1;
+        i2 = (lim2 < 0 || (uint32_t)i2 > (uint32_t)lim2) ? WF_NULL : i2;
+        d2 = (lim2 < 0 || (uint32_t)d2 > (uint32_t)lim2) ? WF_NULL : d2;
+        m = ((uint32_t)m > (uint32_t)limv) ? WF_NULL : m;
+        m = IMAX(m, IMAX(IMAX(i1, i2), IMAX(d1, d2)));
+        oM[k] = m; oI1[k] = i1; oI2[k] = i2; oD1[k] = d1; oD2[k] = d2;
+    }
+}
+
+/* The same step for the modular (score-only, biWFA) aligners, laid out the way WFA2-lib's own compute kernels are:
+ * every row of a slot spans all diagonals and holds WF_NULL outside the level it stores, absent source levels read a
+ * NULL row, so the recurrences of a level are one branch-free loop over [lo, hi] the compiler vectorises; the match
+ * extension follows as a second loop.  Cell for cell the values of wfa_step (tests/test_oracle_golden.py compares the
+ * two on random inputs through SRO_ORACLE_SCALAR_STEP=1). */
+static int g_scalar_step = -1;
+static void wfa_step_scalar(wfa_t *a, int s);
+static void wfa_step_modular(wfa_t *a, int s) {
+    const level_t *Lx = wfa_level(a, s - a->x);
+    const level_t *Lo1 = wfa_level(a, s - a->o1 - a->e1);
+    const level_t *Le1 = wfa_level(a, s - a->e1);
+    const level_t *Lo2 = a->two ? wfa_level(a, s - a->o2 - a->e2) : NULL;
+    const level_t *Le2 = a->two ? wfa_level(a, s - a->e2) : NULL;
+    int lo = INT_MAX, hi = INT_MIN;
+    if (Lx) { lo = IMIN(lo, Lx->lo); hi = IMAX(hi, Lx->hi); }
+    if (Lo1) { lo = IMIN(lo, Lo1->lo - 1); hi = IMAX(hi, Lo1->hi + 1); }
+    if (Le1) { lo = IMIN(lo, Le1->lo - 1); hi = IMAX(hi, Le1->hi + 1); }
+    if (Lo2) { lo = IMIN(lo, Lo2->lo - 1); hi = IMAX(hi, Lo2->hi + 1); }
+    if (Le2) { lo = IMIN(lo, Le2->lo - 1); hi = IMAX(hi, Le2->hi + 1); }
+    level_t *L = wfa_slot(a, s);
+    const int plen = a->w.plen, tlen = a->w.tlen;
+    if (lo <= hi) { lo = IMAX(lo, -plen); hi = IMIN(hi, tlen); }
+    /* every row the loop reads or writes is initialised over [lo - 1, hi + 1] */
+    if (lo <= hi) {
+        const int clo = lo - 1, chi = hi + 1;
+        row_cover(a, (level_t *)Lx, clo, chi); row_cover(a, (level_t *)Lo1, clo, chi); row_cover(a, (level_t *)Le1, clo, chi);
+        if (Lo2) row_cover(a, (level_t *)Lo2, clo, chi);
+        if (Le2) row_cover(a, (level_t *)Le2, clo, chi);
+        row_cover(a, NULL, clo, chi);
+        row_cover(a, L, clo, chi);
+    }
+    /* the slot's old level (s - scope) goes: its cells outside the new range become WF_NULL again */
+    const int sh = a->shift;
+    {
+        const int nlo = lo <= hi ? lo : INT_MAX, nhi = lo <= hi ? hi : INT_MIN;
+        for (int k = L->wlo; k <= L->whi; k++)
+            if (k < nlo || k > nhi) for (int j = 0; j < 5; j++) L->c[j][k + sh] = WF_NULL;
+    }
+    if (lo > hi) { L->score = s; L->lo = 1; L->hi = 0; L->wlo = 1; L->whi = 0; return; }
+    L->score = s; L->wlo = lo; L->whi = hi;
+    const int32_t *restrict mx = (Lx ? Lx->c[SRO_M] : a->nullrow) + sh;
+    const int32_t *restrict mo1 = (Lo1 ? Lo1->c[SRO_M] : a->nullrow) + sh;
+    const int32_t *restrict si1 = (Le1 ? Le1->c[SRO_I1] : a->nullrow) + sh;
+    const int32_t *restrict sd1 = (Le1 ? Le1->c[SRO_D1] : a->nullrow) + sh;
+    const int32_t *restrict mo2 = (Lo2 ? Lo2->c[SRO_M] : a->nullrow) + sh;
+    const int32_t *restrict si2 = (Le2 ? Le2->c[SRO_I2] : a->nullrow) + sh;
+    const int32_t *restrict sd2 = (Le2 ? Le2->c[SRO_D2] : a->nullrow) + sh;
+    int32_t *restrict oM = L->c[SRO_M] + sh, *restrict oI1 = L->c[SRO_I1] + sh, *restrict oI2 = L->c[SRO_I2] + sh;
+    int32_t *restrict oD1 = L->c[SRO_D1] + sh, *restrict oD2 = L->c[SRO_D2] + sh;
+    step_kernel(lo, hi, plen, tlen, a->two, mx, mo1, si1, sd1, mo2, si2, sd2, oM, oI1, oI2, oD1, oD2);
+    int any_lo = INT_MAX, any_hi = INT_MIN;
+    for (int k = lo; k <= hi; k++) {
+        const int32_t m = oM[k];
+        if (m < 0) continue;
+        oM[k] = wf_extend(&a->w, k, m);
+        if (any_lo == INT_MAX) any_lo = k;
+        any_hi = k;
+    }
+    a->cells += (uint64_t)(hi - lo + 1);
+    if (any_lo > any_hi) { L->lo = 1; L->hi = 0; }
+    else { L->lo = any_lo; L->hi = any_hi; }
+}
+
 /* one score step: compute + bound + extend (WFA2 wavefront_compute_affine2p
  * + wavefront_extend_end2end) */
 static void wfa_step(wfa_t *a, int s) {
+    if (a->modular) {
+        if (g_scalar_step < 0) { const char *e = getenv("SRO_ORACLE_SCALAR_STEP"); g_scalar_step = (e && atoi(e)) ? 1 : 0; }
+        if (!g_scalar_step) { wfa_step_modular(a, s); return; }
+    }
+    wfa_step_scalar(a, s);
+}
+static void wfa_step_scalar(wfa_t *a, int s) {
     const level_t *Lx = wfa_level(a, s - a->x);
     const level_t *Lo1 = wfa_level(a, s - a->o1 - a->e1);
     const level_t *Le1 = wfa_level(a, s - a->e1);
@@ -428,11 +552,11 @@ typedef struct {
 static int level_max_ak(const level_t *L) {
     int mx = 0;
     if (!L) return 0;
+    const int32_t *restrict m = L->c[SRO_M] + L->off0;
     for (int k = L->lo; k <= L->hi; k++) {
-        int32_t o = L->c[SRO_M][k + L->off0];
-        if (o < 0) continue;
-        int ak = 2 * o - k;
-        if (ak > mx) mx = ak;
+        const int32_t o = m[k];
+        const int ak = o < 0 ? 0 : 2 * o - k;
+        mx = ak > mx ? ak : mx;
     }
     return mx;
 }
