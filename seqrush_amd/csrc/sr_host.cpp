@@ -589,7 +589,7 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
     // (the blocked kernel has its own ring depth limit, checked by srk_align_blk_supports: it does not inherit the
     // level-synchronous kernel's 32-slot limit)
     // (the blocked kernel wraps its LDS window addresses into 128 KB: static tables + four sequence copies must fit below)
-    if (kblock > 0 && (long long)max_words * 16 + 24 * 1024 <= 128 * 1024) impl = 2;
+    if (kblock > 0 && (long long)max_words * 16 + 36 * 1024 <= 128 * 1024) impl = 2;
     if (const char *e = getenv("SR_ALIGN_IMPL")) {       // (a request for the level-per-pass kernel falls through to kernel 0 when its ring is too shallow)
         const int want = std::max(0, atoi(e)), bfs_ok = std::max(pen.scope, ori.scope) + 1 <= 32;
         if (want < impl) impl = (want == 1 && !bfs_ok) ? 0 : want;
@@ -610,7 +610,7 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
     if (impl == 2 && c->nthreads == 128 && kblock == 10 && !(sm.bits == 2 && c->off16)) kblock = 5;   // (no 128-thread 10-level instance there)
     const bool wave_wg = impl == 2 && (c->nthreads == 64 || (c->nthreads == 128 && kblock == 10));   // lean builds: 16 / 8 pairs per CU
     if (wave_wg) wg_per_cu = c->nthreads == 64 ? 16 : 8;
-    const size_t lds_per_wg = c->lds_bytes + (wave_wg ? 4 : impl == 2 ? 20 : impl ? 28 : 8) * 1024;
+    const size_t lds_per_wg = c->lds_bytes + (wave_wg ? 6 : impl == 2 ? 30 : impl ? 28 : 8) * 1024;   // + static tables
     wg_per_cu = (int)std::min<size_t>((size_t)wg_per_cu, std::max<size_t>(1, (160 * 1024) / lds_per_wg));
     // long sequences: the four LDS copies leave room for two workgroups per CU (C5: 50 KB each) -- give each 8 waves, or
     // the SIMDs hold two waves (C5 subset 3 507 -> 2 200 ms).  512-thread builds: int16 rows; 32-bit searches with the
@@ -618,6 +618,15 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
     if (impl == 2 && !wave_wg && wg_per_cu <= 2 && !getenv("SR_ALIGN_THREADS")) {
         const char *ru_ = getenv("SR_RING_U16");
         if (c->off16 || (kblock == 10 && maxlen <= 57000 && !(ru_ && atoi(ru_) == 0))) c->nthreads = 512;
+    }
+    // deeper blocks (rolled tile, sr_align_blk.inc blk_tile16r): int16 rows, two-piece penalties with o2 + e2 >= the block,
+    // 256-thread workgroups.  SR_BLK_LEVELS=10 keeps the unrolled 10-level tile, =25 asks for 25-level blocks.
+    if (impl == 2 && kblock == 10 && c->off16 && pen.two && c->nthreads == 256 && !wave_wg) {
+        int want = 10;                  // (measured: 20-level blocks move 14 % fewer row bytes and run 6 % slower on C2 -- opt-in)
+        if (const char *e = getenv("SR_BLK_LEVELS")) want = atoi(e);
+        want = std::min(want, srk_align_blk_max_levels());
+        for (int bl = (want / 5) * 5; bl > 10; bl -= 5)
+            if ((bl == 20 || bl == 25) && pen.o2 + pen.e2 >= bl && 2 * pen.scope + 2 * bl + 2 <= SR_BLK_MAK_SLOTS) { kblock = bl; break; }
     }
     const int ring_scope = std::max(pen.scope, ori.scope);
     const int ring_cap = (int)((2 * maxlen + 3 + 7) & ~7ULL);
@@ -633,10 +642,10 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
     const int hist_levels = smax_base + 1 + std::max(kblock, 5);   // + one block of levels (impl 2 computes whole blocks)
     int rmax = smax_base / pen.e1;
     if (pen.two) rmax = std::max(rmax, smax_base / pen.e2);
-    const int hist_w = (2 * (rmax + pen.scope + 2) + 1 + 8 + 32 + 7) & ~7;   // rows hold whole 4-diagonal groups
+    const int hist_w = (2 * (rmax + pen.scope + 2) + 1 + 8 + 64 + 7) & ~7;   // (+ halo groups of the deepest tile either side)   // rows hold whole 4-diagonal groups
     const uint64_t hist_wg = (uint64_t)hist_levels * 5 * (uint64_t)hist_w + (uint64_t)hist_w;   // + NULL row
     // bfs kernel workspace: shared rows (every aligner owns a sub-range) + batched base-case history
-    const int brow = (int)((4 * maxlen + 32 * 64 + 64 + 512 + 7) & ~7ULL);     // per-aligner margins + read slack of the last wave tile
+    const int brow = (int)((4 * maxlen + 32 * 72 + 64 + 512 + 7) & ~7ULL);     // per-aligner margins + read slack of the last wave tile
     int kdepth = std::max(pen.scope + std::max(kblock, 1), ori.scope + 1) + 1;
     // lazy I/D rows (sr_align_blk.inc blk_recompute): the M rows must reach 2 * scope + 2 blocks back
     const char *lz = getenv("SR_LAZY_ID");

@@ -12,7 +12,7 @@
 #define SR_BFS_SEGREC 16             // ints per segment record
 #define SR_BFS_MAXACT 32             // segments searched concurrently (2 aligners each)
 #define SR_BFS_BTCAP 1024
-#define SR_BLK_MAK_SLOTS 80           // ring depth the blocked kernel supports (2 * scope + 2 * block + 2 = 74 for 0,5,8,2,24,1)
+#define SR_BLK_MAK_SLOTS 112          // ring depth the blocked kernel supports (2 * scope + 2 * block + 2 = 74 for 0,5,8,2,24,1)
 
 enum { SR_C_M = 0, SR_C_I1 = 1, SR_C_I2 = 2, SR_C_D1 = 3, SR_C_D2 = 4 };
 // raw WFA2 op codes used in device CIGAR ops: (len << 4) | op
@@ -146,6 +146,7 @@ int srk_graph_induce(const unsigned long long *labels, const uint8_t *bases, con
                      uint32_t *steps, uint8_t *node_base, unsigned long long *hkeys, uint32_t *hvals,
                      uint64_t hcap, uint32_t *eslot, unsigned long long *edges, uint32_t *tile_sum,
                      uint32_t *counts, int *error_flag, void *stream);
+int srk_align_blk_max_levels(void);                                // deepest block of the build (static LDS tables)
 int srk_align_blk_supports(const SrPen *pen, const SrPen *ori);   // levels per block, 0 = no blocked instance
 int srk_labels32(unsigned long long *nodes, uint64_t uf_size, unsigned long long *minarr, uint32_t *labels, int *error_flag,
                  void *stream);

@@ -372,7 +372,9 @@ class Context:
                     ticks_orientation=int(out[6]), ticks_breakpoint=int(out[7]), ticks_base=int(out[8]),
                     bp_passes=int(out[9]), ticks_pair=int(out[10]), tk_pass=int(out[11]),
                     tk_barrier=int(out[12]), tk_control=int(out[13]), tk_phase2=int(out[14]),
-                    tk_tail=int(out[15]))
+                    tk_tail=int(out[15]), bp_filter_units=int(out[19]), bp_candidates=int(out[20]),
+                    bp_exact_units=int(out[21]), bp_rounds=int(out[22]), tk_backtrace=int(out[23]), tk_emit=int(out[24]),
+                    st_wait_cycles=int(out[25]), st_body_cycles=int(out[26]), st_tiles=int(out[27]), st_ext_iters=int(out[28]))
 
     def close(self):
         if self._h:
