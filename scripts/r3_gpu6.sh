@@ -1,0 +1,24 @@
+#!/bin/bash
+# round 3, GPU call 6: E in 13-level load blocks, setup folded into control, tighter base-case packing
+set -o pipefail
+mkdir -p gpurun_out
+R=$GRAFT_REPO_ROOT
+cd $R
+show() { python - "$1" "$2" <<'PY'
+import json,sys
+d=json.loads(open(sys.argv[2]).read().strip().split("\n")[-1])
+r=d["roofline"]; k=d["kernels"]
+print(sys.argv[1], "ms/step", round(d["ms_per_step"],2), "align", round(r["kernel_ms"],2), "wsGB", round(d["config"]["workspace"]["workspace_bytes"]/1e9,1),
+      {x:k[x] for x in k if x.startswith(("tk","ticks_b","ticks_p","bp_r","bp_e","bp_c","base_")) and k[x]})
+PY
+}
+timeout -k 10 300 python scripts/gpu_parity_quick.py > gpurun_out/quick.log 2>&1; echo "quick rc=$?"; tail -2 gpurun_out/quick.log
+grep -q "ALL OK" gpurun_out/quick.log || { grep -n "MISMATCH\|Error\|error" gpurun_out/quick.log | head; exit 1; }
+for v in "SR_X=1" "SR_HIST_JOBS=16" "SR_BLK_LEVELS=20"; do
+  env $v timeout -k 10 200 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-host-stages > gpurun_out/f.json 2> gpurun_out/f.err || { tail -5 gpurun_out/f.err; exit 1; }
+  show "plain $v" gpurun_out/f.json
+  env $v SR_PROFILE_TICKS=1 timeout -k 10 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-stages > gpurun_out/ft.json 2> gpurun_out/ft.err || { tail -5 gpurun_out/ft.err; exit 1; }
+  show "ticks $v" gpurun_out/ft.json
+done
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "not full_size_c4_parity and not full_size_c5" > gpurun_out/t6.log 2>&1
+echo "pytest rc=$?"; tail -5 gpurun_out/t6.log

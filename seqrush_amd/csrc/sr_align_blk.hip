@@ -46,18 +46,6 @@ static int launch_blk10(const SrAlignArgs *a, int nwg, size_t lds_bytes, hipStre
     hipLaunchKernelGGL((sr_align_blk_kernel<OT, NT, TWO, 10, 2, 1, PROF, 5, 10, RT>), dim3(nwg), dim3(NT), lds_bytes, st, *a);
     return (int)hipGetLastError();
 }
-// rolled tile (sr_align_blk.inc blk_tile16r): the same exact-penalty instance with blocks of BL = 20 (25) levels, int16 rows;
-// needs o2 + e2 >= BL (the M[s - o2 - e2] rows of a block are rows older blocks wrote)
-template <int NT, bool TWO, int BL, bool PROF = false>
-static int launch_blkr(const SrAlignArgs *a, int nwg, size_t lds_bytes, hipStream_t st) {
-    if (lds_bytes > 16 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)sr_align_blk_kernel<int16_t, NT, TWO, BL, 2, 1, PROF, 5, 10, int16_t>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return (int)e;
-    }
-    hipLaunchKernelGGL((sr_align_blk_kernel<int16_t, NT, TWO, BL, 2, 1, PROF, 5, 10, int16_t>), dim3(nwg), dim3(NT), lds_bytes, st, *a);
-    return (int)hipGetLastError();
-}
 // penalty sets this build has a blocked instance for (host side asks before choosing impl 2): levels per block
 #if SR_SYMBITS == 2 && !defined(SR_BLK_WAVE)
 extern "C" int srk_align_blk_max_levels(void) { return KB_MAX; }
@@ -90,19 +78,6 @@ extern "C" int SRK_NAME(srk_align_blkw)(const SrAlignArgs *a, int nwg, size_t ld
 extern "C" int SRK_NAME(srk_align_blk)(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, int nthreads, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     const bool two = a->pen.two != 0;
-#ifndef SR_BLK_WAVE
-    if (a->kblock > 10) {                       // rolled tile: int16 rows, two-piece penalties, 256 threads (host: load_impl)
-        if (!(off16 && two && nthreads == 256)) return (int)hipErrorInvalidValue;
-#if SR_KB_MAX >= 25
-        if (a->kblock == 25) return launch_blkr<256, true, 25>(a, nwg, lds_bytes, st);
-#endif
-#if SR_SYMBITS == 2
-        if (a->kblock == 20 && a->profile_ticks) return launch_blkr<256, true, 20, true>(a, nwg, lds_bytes, st);
-#endif
-        if (a->kblock == 20) return launch_blkr<256, true, 20>(a, nwg, lds_bytes, st);
-        return (int)hipErrorInvalidValue;
-    }
-#endif
     if (a->kblock == 10) {
         if (off16) {
 #if SR_SYMBITS == 2

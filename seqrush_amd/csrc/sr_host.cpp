@@ -610,7 +610,9 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
     if (impl == 2 && c->nthreads == 128 && kblock == 10 && !(sm.bits == 2 && c->off16)) kblock = 5;   // (no 128-thread 10-level instance there)
     const bool wave_wg = impl == 2 && (c->nthreads == 64 || (c->nthreads == 128 && kblock == 10));   // lean builds: 16 / 8 pairs per CU
     if (wave_wg) wg_per_cu = c->nthreads == 64 ? 16 : 8;
-    const size_t lds_per_wg = c->lds_bytes + (wave_wg ? 6 : impl == 2 ? 30 : impl ? 28 : 8) * 1024;   // + static tables
+    size_t lds_static = (size_t)(wave_wg ? 6 : impl == 2 ? 22 : impl ? 28 : 8) * 1024;      // static tables of the kernel (upper estimate)
+    if (const char *e = getenv("SR_STATIC_LDS_KB")) lds_static = (size_t)std::max(1, atoi(e)) * 1024;       // (A/B builds with other table sizes)
+    const size_t lds_per_wg = c->lds_bytes + lds_static;
     wg_per_cu = (int)std::min<size_t>((size_t)wg_per_cu, std::max<size_t>(1, (160 * 1024) / lds_per_wg));
     // long sequences: the four LDS copies leave room for two workgroups per CU (C5: 50 KB each) -- give each 8 waves, or
     // the SIMDs hold two waves (C5 subset 3 507 -> 2 200 ms).  512-thread builds: int16 rows; 32-bit searches with the
@@ -618,15 +620,6 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
     if (impl == 2 && !wave_wg && wg_per_cu <= 2 && !getenv("SR_ALIGN_THREADS")) {
         const char *ru_ = getenv("SR_RING_U16");
         if (c->off16 || (kblock == 10 && maxlen <= 57000 && !(ru_ && atoi(ru_) == 0))) c->nthreads = 512;
-    }
-    // deeper blocks (rolled tile, sr_align_blk.inc blk_tile16r): int16 rows, two-piece penalties with o2 + e2 >= the block,
-    // 256-thread workgroups.  SR_BLK_LEVELS=10 keeps the unrolled 10-level tile, =25 asks for 25-level blocks.
-    if (impl == 2 && kblock == 10 && c->off16 && pen.two && c->nthreads == 256 && !wave_wg) {
-        int want = 10;                  // (measured: 20-level blocks move 14 % fewer row bytes and run 6 % slower on C2 -- opt-in)
-        if (const char *e = getenv("SR_BLK_LEVELS")) want = atoi(e);
-        want = std::min(want, srk_align_blk_max_levels());
-        for (int bl = (want / 5) * 5; bl > 10; bl -= 5)
-            if ((bl == 20 || bl == 25) && pen.o2 + pen.e2 >= bl && 2 * pen.scope + 2 * bl + 2 <= SR_BLK_MAK_SLOTS) { kblock = bl; break; }
     }
     const int ring_scope = std::max(pen.scope, ori.scope);
     const int ring_cap = (int)((2 * maxlen + 3 + 7) & ~7ULL);
@@ -653,7 +646,7 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
     if (lazy_id) kdepth = std::max(kdepth, 2 * pen.scope + 2 * kblock + 2);
     uint64_t bring_wg = ((uint64_t)(ring_scope + 1) + 4ULL * ring_hot + 4ULL * (ring_scope + 1) + 2ULL) * (uint64_t)brow;   // + NULL row + U row
     // impl 2: chunk-major ring (sr_align_blk.inc KRows): 256-cell pieces of all 5 * depth + 2 rows together, + 2 pieces of read slack
-    if (impl == 2) bring_wg = ((uint64_t)brow / 256 + 2ULL) * ((uint64_t)kdepth * 5 + 2ULL) * 256ULL + 1024;
+    if (impl == 2) bring_wg = ((uint64_t)brow / 256 + 2ULL) * ((uint64_t)kdepth * 5 + 3ULL) * 256ULL + 1024;      // rows: 5 x depth + NULL + U + trash
     // (the blocked kernel addresses a workgroup's rows as base + 32-bit byte offset)
     // 32-bit searches below 57 k keep their ring as uint16 (offset + 8192): half the row bytes (C5 is bound by them).
     // The exact 10-level instance at 256 threads has that build; SR_RING_U16=0 keeps 32-bit rows.
@@ -663,7 +656,16 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
     if (impl == 2 && bring_wg * rsz >= (1ULL << 32)) return fail(SR_ERR_UNSUPPORTED, "sequences too long for the device row workspace (4 GB per workgroup)");
     int bbase_jobs = wave_wg ? (c->nthreads == 64 ? 4 : 8) : 16;
     if (const char *e = getenv("SR_BFS_BASE_JOBS")) bbase_jobs = std::max(1, std::min(16, atoi(e)));
-    const uint64_t bhist_wg = ((uint64_t)hist_levels * 5 + 1) * (uint64_t)bbase_jobs * (uint64_t)hist_w + 1024;
+    // base-case history of a workgroup.  Level-per-pass kernel: bbase_jobs fixed slots of the worst-case width.  Blocked
+    // kernel: hist_cap cells that every batch lays out for the levels and widths its jobs really need (sr_align_blk.inc);
+    // one worst-case job always fits, the default holds 5 of them (C2: 13 MB instead of 40.6 -- a pair's 16 base cases of
+    // score ~150 still run as one batch; SR_HIST_JOBS=n: n of them).
+    const uint64_t hist_worst = (uint64_t)hist_levels * 5 * (uint64_t)hist_w;
+    uint64_t hist_cap = hist_worst * 5;
+    if (const char *e = getenv("SR_HIST_JOBS")) hist_cap = hist_worst * (uint64_t)std::max(1, std::min(16, atoi(e)));
+    const uint64_t hist_nul_w = (uint64_t)bbase_jobs * (uint64_t)hist_w;
+    const uint64_t bhist_wg = impl == 2 ? ((hist_cap + hist_nul_w + 256 + 1024 + 7) & ~7ULL)      // data, NULL row, trash cells, slack
+                                        : ((uint64_t)hist_levels * 5 + 1) * (uint64_t)bbase_jobs * (uint64_t)hist_w + 1024;
     const uint64_t bseg_wg = 2ULL * SR_BFS_MAXSEG * SR_BFS_SEGREC * 4;          // bytes
     const uint64_t bbt_wg = (uint64_t)bbase_jobs * SR_BFS_BTCAP * 4;           // bytes
     // impl 2: every diagonal of every level of a block can be a breakpoint candidate at worst
@@ -800,6 +802,7 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
     a.hist_wg_stride = hist_wg; a.hist_w = hist_w; a.hist_levels = hist_levels;
     { const char *pt_ = getenv("SR_PROFILE_TICKS"); a.profile_ticks = (pt_ && atoi(pt_) != 0) ? 1 : 0; }
     a.impl = impl; a.kdepth = kdepth; a.kblock = kblock; a.lazy_id = lazy_id; a.ring_u16 = ring_u16; a.ori_levels = getenv("SR_ORIENT_LEVELS") ? 1 : 0; a.bring_wg_stride = bring_wg; a.brow = brow; a.bhist_wg_stride = bhist_wg; a.bbase_jobs = bbase_jobs;
+    a.hist_cap = hist_cap; a.hist_nul_w = (uint32_t)hist_nul_w; a.hist_stride = (uint32_t)hist_nul_w;
     a.cigar_base = c->d_cbase; a.counters = c->d_counters; a.error_flag = c->d_error;
     SrUniteArgs &u = c->ua;
     memset(&u, 0, sizeof(u));

@@ -74,8 +74,12 @@ struct SrAlignArgs {
                                //   cold [(ring_scope+1)][4] | NULL row ; every aligner owns a sub-range of each row
     uint64_t bring_wg_stride;
     int brow;
-    void *bhist;               // [hist_levels][5][bbase_jobs * hist_w] + NULL row
+    void *bhist;               // level-per-pass kernel: [hist_levels][5][bbase_jobs * hist_w] + NULL row; blocked kernel: hist_cap cells
+                               // that every batch of base cases lays out as [levels of the batch][5][sum of its widths], + a NULL row
     uint64_t bhist_wg_stride;
+    uint64_t hist_cap;         // blocked kernel: cells of a workgroup's history (>= hist_levels * 5 * hist_w: one worst-case base case)
+    uint32_t hist_stride;      // level-per-pass kernel: cells per history row (bbase_jobs * hist_w)
+    uint32_t hist_nul_w;       // blocked kernel: cells of the NULL row (widest batch: bbase_jobs * hist_w)
     int bbase_jobs;
     int *bseg;                 // 2 segment lists of SR_BFS_MAXSEG records x SR_BFS_SEGREC ints
     uint32_t *bbt;             // [bbase_jobs][SR_BFS_BTCAP] reversed run-length ops of finished base cases
