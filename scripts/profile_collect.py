@@ -13,7 +13,7 @@ VALU_PEAK_PER_SIMD = 0.5                    # wave-instructions per cycle and SI
 
 
 def kname(n):
-    if "sr_align_blk_kernel" in n or "sr_align_bfs_kernel" in n or "sr_align_kernel" in n:
+    if "sr_align_blk_kernel" in n or "sr_align_bfs_kernel" in n:
         return "align"
     if "sr_orient_kernel" in n or "sr_orient_blk_kernel" in n:
         return "orient"

@@ -1,5 +1,5 @@
 """Stress for workgroups that align many pairs one after the other: the blocked kernel (default) against the
-level-per-pass kernels (SR_ALIGN_IMPL=1, or 0 where the penalties exceed its ring; independent tile code) on the same
+level-per-pass kernel (SR_ALIGN_IMPL=1; independent tile code) on the same
 inputs with few workgroups -- scores, strands and the union-find partition must agree (the number of device run-length
 ops is not compared: kernels may split a run at a segment boundary, the CIGAR is the same).  usage: python scripts/stress_multi.py [rounds]"""
 import sys, os, random, time

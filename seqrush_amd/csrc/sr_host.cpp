@@ -431,13 +431,46 @@ static SymMap make_symmap(const sr_seqset *seqs) {
     return m;
 }
 
-static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const uint32_t *eq, const uint32_t *et,
-                     uint64_t ecount, bool explicit_pairs) {
-    if (!c || !seqs || !p) return fail(SR_ERR_INVALID, "null argument");
-    if (seqs->n == 0) return fail(SR_ERR_INVALID, "no sequences");
-    HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    free_dev(c);
+// A load runs these steps in order (round 3: one function each):
+//   load_index        lengths, offsets, penalties, parameter checks
+//   pack_sequences    byte -> symbol map, packed copies (forward / reverse complement [/ reversed / complemented])
+//   upload_sequences  raw bytes + packed words + per-sequence tables to the device
+//   build_pair_list   enumeration or explicit list, sparsification (tree: k-mer sketches on the device), shard
+//   plan_launch       which kernel, workgroup shape, per-workgroup workspace, CIGAR arena and batches, workgroup count
+//   alloc_workspace   device allocations, per-pair arrays, kernel arguments, sizing report
+struct PackedSeqs {
+    SymMap sm;
+    int per_word = 16, ncopies = 2;
+    std::vector<uint64_t> woff[4];                 // word offset of every sequence's copy k (k = 2, 3 alias 1, 0 for 2-bit buffers)
+    std::vector<uint32_t> words;
+};
+struct SeqDev { uint32_t *words = nullptr; uint64_t *woff[4] = {nullptr, nullptr, nullptr, nullptr}; uint64_t *goff = nullptr; uint32_t *len = nullptr; };
+struct Plan {
+    // kernel + launch shape
+    int impl = 1, kblock = 0, wg_per_cu = 4, cus = 256, lazy_id = 0, ring_u16 = 0, bbase_jobs = 16;
+    bool wave_wg = false;
+    uint32_t max_words = 0;
+    size_t osz = 2, rsz = 2;
+    // per-workgroup workspace (cells unless stated)
+    int ring_scope = 0, ring_hot = 0, hist_levels = 0, hist_w = 0, brow = 0, kdepth = 0;
+    uint64_t bring_wg = 0, bhist_wg = 0, hist_cap = 0, hist_nul_w = 0, bseg_wg = 0, bbt_wg = 0, bcl_wg = 0, per_wg_bytes = 0;
+    // memory budget
+    size_t free_b = 0;
+    uint64_t arena_ops = 0, left = 0, max_reserve = 4;
+    uint32_t nbatch = 0, max_batch_pairs = 0;
+    int nwg = 1;
+    uint64_t oring_bytes = 0;
+};
+#define DEV_UPLOAD(field, T, hostvec)                                                         \
+    do {                                                                                      \
+        const auto &hv_ = (hostvec);                                                          \
+        void *d_ = nullptr;                                                                   \
+        if ((r = dev_alloc(c, &d_, hv_.size() * sizeof(T)))) return r;                        \
+        HIPCHK(hipMemcpyAsync(d_, hv_.data(), hv_.size() * sizeof(T), hipMemcpyHostToDevice, c->stream)); \
+        field = (T *)d_;                                                                      \
+    } while (0)
+
+static int load_index(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, bool explicit_pairs, SrPen *pen, SrPen *ori, uint64_t *maxlen_out) {
     c->prm = *p;
     const uint32_t n = seqs->n;
     c->n = n;
@@ -453,12 +486,12 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
         c->len[i] = (uint32_t)L; c->goff[i] = seqs->offsets[i];
         maxlen = std::max(maxlen, L);
     }
+    *maxlen_out = maxlen;
     c->total_len = seqs->offsets[n];
     c->uf_size = (c->total_len << 1) + 2;          // bidirected_union_find.rs:16-24
-    SrPen pen, ori;
     int r;
-    if ((r = make_pen(*p, false, &pen))) return r;
-    if ((r = make_pen(*p, true, &ori))) return r;
+    if ((r = make_pen(*p, false, pen))) return r;
+    if ((r = make_pen(*p, true, ori))) return r;
     if (p->memory_mode != SR_MEM_ULTRALOW)
         return fail(SR_ERR_UNSUPPORTED, "memory_mode must be SR_MEM_ULTRALOW (biWFA, what the reference selects: src/wfa.rs:57); "
                                         "the device keeps full wavefront history only for biWFA's base cases");
@@ -468,90 +501,98 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
     if (p->shard_count == 0 || p->shard_rank >= p->shard_count) return fail(SR_ERR_INVALID, "bad shard");
     if (!explicit_pairs && (uint64_t)n * n > 0xffffffffULL)
         return fail(SR_ERR_UNSUPPORTED, "more than 2^32 ordered pairs: sparsify (-x) or pass an explicit pair list");
-    void *d;
-    // ---- raw bytes on the device (sketches, graph induction)
-    if ((r = dev_alloc(c, &d, c->total_len))) return r;
-    c->d_bases = (uint8_t *)d;
-    HIPCHK(hipMemcpyAsync(c->d_bases, seqs->bases, c->total_len, hipMemcpyHostToDevice, c->stream));
-    // ---- packed symbol buffer: forward, reverse complement (+ reversed, complemented when the alphabet is not plain
-    //      ACGT: seqrush's complement maps lower case to upper case, so "equal complements <=> equal bases" fails)
-    const SymMap sm = make_symmap(seqs);
-    c->symbits = sm.bits;
-    const int per_word = 32 / sm.bits;
-    const int ncopies = sm.bits == 2 ? 2 : 4;
-    std::vector<uint64_t> woff[4];
-    for (int k = 0; k < 4; k++) woff[k].assign(n, 0);
+    return SR_OK;
+}
+
+// packed symbol buffer: forward, reverse complement (+ reversed, complemented when the alphabet is not plain ACGT: seqrush's
+// complement maps lower case to upper case, so "equal complements <=> equal bases" fails); one pad word either side of a copy
+static void pack_sequences(const sr_ctx *c, const sr_seqset *seqs, PackedSeqs &pk) {
+    const uint32_t n = seqs->n;
+    pk.sm = make_symmap(seqs);
+    pk.per_word = 32 / pk.sm.bits;
+    pk.ncopies = pk.sm.bits == 2 ? 2 : 4;
+    for (int k = 0; k < 4; k++) pk.woff[k].assign(n, 0);
     uint64_t words = 0;
     for (uint32_t i = 0; i < n; i++) {
-        const uint64_t w = (c->len[i] + per_word - 1) / per_word;
-        for (int k = 0; k < ncopies; k++) { woff[k][i] = words + 1; words += w + 2; }
-        if (ncopies == 2) { woff[2][i] = woff[1][i]; woff[3][i] = woff[0][i]; }      // aliases (see sr_align_blk.inc)
+        const uint64_t w = (c->len[i] + pk.per_word - 1) / pk.per_word;
+        for (int k = 0; k < pk.ncopies; k++) { pk.woff[k][i] = words + 1; words += w + 2; }
+        if (pk.ncopies == 2) { pk.woff[2][i] = pk.woff[1][i]; pk.woff[3][i] = pk.woff[0][i]; }      // aliases (see sr_align_blk.inc)
     }
-    std::vector<uint32_t> packed(words, 0);
+    pk.words.assign(words, 0);
+    const SymMap &sm = pk.sm;
     for (uint32_t i = 0; i < n; i++) {
         const uint8_t *b = seqs->bases + seqs->offsets[i];
         const uint64_t L = c->len[i];
         for (uint64_t j = 0; j < L; j++) {
-            const unsigned sh = (unsigned)(j % per_word) * sm.bits;
-            const uint64_t wi = j / per_word;
-            packed[woff[0][i] + wi] |= (uint32_t)sm.code[b[j]] << sh;                          // forward
-            packed[woff[1][i] + wi] |= (uint32_t)sm.code[comp_base(b[L - 1 - j])] << sh;      // reverse complement
-            if (ncopies == 4) {
-                packed[woff[2][i] + wi] |= (uint32_t)sm.code[b[L - 1 - j]] << sh;              // reversed
-                packed[woff[3][i] + wi] |= (uint32_t)sm.code[comp_base(b[j])] << sh;           // complemented
+            const unsigned sh = (unsigned)(j % pk.per_word) * sm.bits;
+            const uint64_t wi = j / pk.per_word;
+            pk.words[pk.woff[0][i] + wi] |= (uint32_t)sm.code[b[j]] << sh;                          // forward
+            pk.words[pk.woff[1][i] + wi] |= (uint32_t)sm.code[comp_base(b[L - 1 - j])] << sh;      // reverse complement
+            if (pk.ncopies == 4) {
+                pk.words[pk.woff[2][i] + wi] |= (uint32_t)sm.code[b[L - 1 - j]] << sh;              // reversed
+                pk.words[pk.woff[3][i] + wi] |= (uint32_t)sm.code[comp_base(b[j])] << sh;           // complemented
             }
         }
     }
-    SrAlignArgs &a = c->aa;
-    memset(&a, 0, sizeof(a));
-#define DEV_UPLOAD(field, T, hostvec)                                                         \
-    do {                                                                                      \
-        const auto &hv_ = (hostvec);                                                          \
-        if ((r = dev_alloc(c, &d, hv_.size() * sizeof(T)))) return r;                         \
-        HIPCHK(hipMemcpyAsync(d, hv_.data(), hv_.size() * sizeof(T), hipMemcpyHostToDevice, c->stream)); \
-        field = (T *)d;                                                                       \
-    } while (0)
-    uint32_t *d_words; uint64_t *d_w[4], *d_goff; uint32_t *d_len, *d_pq, *d_pt;
-    DEV_UPLOAD(d_words, uint32_t, packed);
-    DEV_UPLOAD(d_w[0], uint64_t, woff[0]);
-    DEV_UPLOAD(d_w[1], uint64_t, woff[1]);
-    if (ncopies == 4) { DEV_UPLOAD(d_w[2], uint64_t, woff[2]); DEV_UPLOAD(d_w[3], uint64_t, woff[3]); }
-    else { d_w[2] = d_w[1]; d_w[3] = d_w[0]; }
-    DEV_UPLOAD(d_len, uint32_t, c->len);
-    DEV_UPLOAD(d_goff, uint64_t, c->goff);
+}
+
+static int upload_sequences(sr_ctx *c, const sr_seqset *seqs, const PackedSeqs &pk, SeqDev &sd) {
+    int r;
+    void *d;
+    if ((r = dev_alloc(c, &d, c->total_len))) return r;                // raw bytes (sketches, graph induction)
+    c->d_bases = (uint8_t *)d;
+    HIPCHK(hipMemcpyAsync(c->d_bases, seqs->bases, c->total_len, hipMemcpyHostToDevice, c->stream));
+    DEV_UPLOAD(sd.words, uint32_t, pk.words);
+    DEV_UPLOAD(sd.woff[0], uint64_t, pk.woff[0]);
+    DEV_UPLOAD(sd.woff[1], uint64_t, pk.woff[1]);
+    if (pk.ncopies == 4) { DEV_UPLOAD(sd.woff[2], uint64_t, pk.woff[2]); DEV_UPLOAD(sd.woff[3], uint64_t, pk.woff[3]); }
+    else { sd.woff[2] = sd.woff[1]; sd.woff[3] = sd.woff[0]; }
+    DEV_UPLOAD(sd.len, uint32_t, c->len);
+    DEV_UPLOAD(sd.goff, uint64_t, c->goff);
+    HIPCHK(hipStreamSynchronize(c->stream));                           // (the host vectors may go away after this)
+    return SR_OK;
+}
+
+// `tree:` sparsification: bottom-1000 sketches, pairwise similarities and the k-nearest / k-farthest selection on the device
+static int tree_selection(sr_ctx *c, const sr_params *p, const SeqDev &sd, std::vector<uint8_t> &sel) {
+    const uint32_t n = c->n;
+    const int S = 1000;
+    std::vector<uint32_t> npad(n);
+    uint64_t stride = 2;
+    for (uint32_t i = 0; i < n; i++) { uint32_t v = 2; while (v < c->len[i]) v <<= 1; npad[i] = v; stride = std::max<uint64_t>(stride, v); }
+    struct Tmp { std::vector<void *> v; ~Tmp() { for (void *q : v) (void)hipFree(q); } } tmp;
+    auto talloc = [&](size_t bytes) -> void * { void *q = nullptr; if (hipMalloc(&q, bytes ? bytes : 16) != hipSuccess) return nullptr; tmp.v.push_back(q); return q; };
+    unsigned long long *d_scr = (unsigned long long *)talloc((size_t)n * stride * 8);
+    unsigned long long *d_sk = (unsigned long long *)talloc((size_t)n * S * 8);
+    uint32_t *d_skn = (uint32_t *)talloc((size_t)n * 4), *d_npad = (uint32_t *)talloc((size_t)n * 4);
+    uint32_t *d_sh = (uint32_t *)talloc((size_t)n * n * 4), *d_dn = (uint32_t *)talloc((size_t)n * n * 4);
+    uint8_t *d_sel = (uint8_t *)talloc((size_t)n * n);
+    if (!d_scr || !d_sk || !d_skn || !d_npad || !d_sh || !d_dn || !d_sel) return fail(SR_ERR_NOMEM, "not enough device memory for the k-mer sketches");
+    HIPCHK(hipMemcpyAsync(d_npad, npad.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(d_sel, 0, (size_t)n * n, c->stream));
+    HIPCHK(hipMemsetAsync(d_sh, 0, (size_t)n * n * 4, c->stream));
+    HIPCHK(hipMemsetAsync(d_dn, 0, (size_t)n * n * 4, c->stream));
+    if (srk_sketch(c->d_bases, sd.goff, sd.len, n, (int)p->tree_kmer, S, d_scr, stride, d_npad, d_sk, d_skn, c->stream) ||
+        srk_jaccard(d_sk, d_skn, n, S, d_sh, d_dn, c->stream) ||
+        srk_knn_select(d_sh, d_dn, n, (int)std::min<uint32_t>(p->tree_k_nearest, n), (int)std::min<uint32_t>(p->tree_k_farthest, n), d_sel, c->stream))
+        return fail(SR_ERR_HIP, "sketch kernel launch failed");
+    sel.resize((size_t)n * n);
     HIPCHK(hipStreamSynchronize(c->stream));
-    // ---- ordered pair list: enumeration / explicit list, sparsification (tree: sketches on the device), shard
+    HIPCHK(hipMemcpy(sel.data(), d_sel, (size_t)n * n, hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+
+// ordered pair list of this rank + what follows from it: DP cells, worst-case CIGAR reserve per pair, divergence thresholds
+static int build_pair_list(sr_ctx *c, const sr_params *p, const SeqDev &sd, const uint32_t *eq, const uint32_t *et, uint64_t ecount,
+                           bool explicit_pairs, std::vector<int32_t> &max_score, uint64_t *max_reserve) {
+    const uint32_t n = c->n;
     if (explicit_pairs) {
         c->pair_q.assign(eq, eq + ecount); c->pair_t.assign(et, et + ecount);
         for (uint64_t i = 0; i < ecount; i++)
             if (eq[i] >= n || et[i] >= n) return fail(SR_ERR_INVALID, "pair index out of range");
     } else {
         std::vector<uint8_t> sel;
-        if (p->sparsify_kind == SR_SPARSE_TREE && n > 1) {
-            const int S = 1000;
-            std::vector<uint32_t> npad(n);
-            uint64_t stride = 2;
-            for (uint32_t i = 0; i < n; i++) { uint32_t v = 2; while (v < c->len[i]) v <<= 1; npad[i] = v; stride = std::max<uint64_t>(stride, v); }
-            struct Tmp { std::vector<void *> v; ~Tmp() { for (void *q : v) (void)hipFree(q); } } tmp;
-            auto talloc = [&](size_t bytes) -> void * { void *q = nullptr; if (hipMalloc(&q, bytes ? bytes : 16) != hipSuccess) return nullptr; tmp.v.push_back(q); return q; };
-            unsigned long long *d_scr = (unsigned long long *)talloc((size_t)n * stride * 8);
-            unsigned long long *d_sk = (unsigned long long *)talloc((size_t)n * S * 8);
-            uint32_t *d_skn = (uint32_t *)talloc((size_t)n * 4), *d_npad = (uint32_t *)talloc((size_t)n * 4);
-            uint32_t *d_sh = (uint32_t *)talloc((size_t)n * n * 4), *d_dn = (uint32_t *)talloc((size_t)n * n * 4);
-            uint8_t *d_sel = (uint8_t *)talloc((size_t)n * n);
-            if (!d_scr || !d_sk || !d_skn || !d_npad || !d_sh || !d_dn || !d_sel) return fail(SR_ERR_NOMEM, "not enough device memory for the k-mer sketches");
-            HIPCHK(hipMemcpyAsync(d_npad, npad.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
-            HIPCHK(hipMemsetAsync(d_sel, 0, (size_t)n * n, c->stream));
-            HIPCHK(hipMemsetAsync(d_sh, 0, (size_t)n * n * 4, c->stream));
-            HIPCHK(hipMemsetAsync(d_dn, 0, (size_t)n * n * 4, c->stream));
-            if (srk_sketch(c->d_bases, d_goff, d_len, n, (int)p->tree_kmer, S, d_scr, stride, d_npad, d_sk, d_skn, c->stream) ||
-                srk_jaccard(d_sk, d_skn, n, S, d_sh, d_dn, c->stream) ||
-                srk_knn_select(d_sh, d_dn, n, (int)std::min<uint32_t>(p->tree_k_nearest, n), (int)std::min<uint32_t>(p->tree_k_farthest, n), d_sel, c->stream))
-                return fail(SR_ERR_HIP, "sketch kernel launch failed");
-            sel.resize((size_t)n * n);
-            HIPCHK(hipStreamSynchronize(c->stream));
-            HIPCHK(hipMemcpy(sel.data(), d_sel, (size_t)n * n, hipMemcpyDeviceToHost));
-        }
+        if (p->sparsify_kind == SR_SPARSE_TREE && n > 1) { const int r = tree_selection(c, p, sd, sel); if (r) return r; }
         enumerate_pairs(n, *p, sel.empty() ? nullptr : sel.data(), c->pair_q, c->pair_t);
     }
     c->total_pairs_all_ranks = c->pair_q.size();
@@ -560,231 +601,240 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
     const uint32_t np = (uint32_t)c->pair_q.size();
     c->dp_cells = 0;
     c->cigar_base.assign((size_t)np + 1, 0);
-    std::vector<int32_t> max_score(std::max<uint32_t>(np, 1), INT_MAX);
-    uint64_t max_reserve = 4;
+    max_score.assign(std::max<uint32_t>(np, 1), INT_MAX);
+    *max_reserve = 4;
     for (uint32_t i = 0; i < np; i++) {
         const uint64_t lq = c->len[c->pair_q[i]], lt = c->len[c->pair_t[i]];
         c->dp_cells += lq * lt;
         c->cigar_base[i + 1] = c->cigar_base[i] + lq + lt + 2;
-        max_reserve = std::max(max_reserve, lq + lt + 2);
+        *max_reserve = std::max(*max_reserve, lq + lt + 2);
         if (p->max_divergence >= 0.0) max_score[i] = max_score_for_divergence(*p, std::min(lq, lt), p->max_divergence);
     }
-    // ---- geometry
+    return SR_OK;
+}
+
+// kernel choice and workgroup shape.  impl 2 = score-blocked wave-tiled kernel (when this build has an instance for the
+// penalties), impl 1 = level-synchronous kernel (any penalties; rings deeper than 32 levels take its wide instance)
+static int plan_kernel(sr_ctx *c, const PackedSeqs &pk, const SrPen &pen, const SrPen &ori, uint64_t maxlen, uint32_t np, Plan &pl) {
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, c->device));
-    const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    pl.cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const int cus = pl.cus, bits = pk.sm.bits;
     c->off16 = maxlen <= 32000 ? 1 : 0;
-    const size_t osz = c->off16 ? 2 : 4;
-    const uint32_t max_words = (uint32_t)((maxlen + per_word - 1) / per_word + 2);
-    c->lds_bytes = (size_t)max_words * 3 * 4;          // query fwd / rc + target fwd
+    pl.osz = c->off16 ? 2 : 4;
+    pl.max_words = (uint32_t)((maxlen + pk.per_word - 1) / pk.per_word + 2);
+    c->lds_bytes = (size_t)pl.max_words * 3 * 4;          // query fwd / rc + target fwd
     if ((long long)c->lds_bytes > (long long)srk_align_max_lds())
-        return fail(SR_ERR_UNSUPPORTED, "sequences too long to stage in LDS (limit ~ 200 kb per sequence at 2 bits per base)");
-    // implementation: 1 = level-synchronous ("bfs") kernel, 0 = one-segment-at-a-time kernel
-    // 2 = score-blocked wave-tiled kernel (when this build has an instance for the penalties)
-    int impl = (std::max(pen.scope, ori.scope) + 1 <= 32) ? 1 : 0;
-    int kblock = srk_align_blk_supports(&pen, &ori);
+        return fail(SR_ERR_UNSUPPORTED, "sequences too long to stage in LDS (limit ~ 170 kb per sequence at 2 bits per base)");
+    pl.impl = 1;
+    pl.kblock = srk_align_blk_supports(&pen, &ori);
     // SR_BLK_LEVELS=5: the generic 5-level instance instead of the exact-penalty 10-level one (A/B runs, tests)
-    if (const char *e = getenv("SR_BLK_LEVELS")) { if (atoi(e) == 5 && kblock == 10) kblock = 5; }
-    // impl 2 also stages the reversed target (4 regions) and has ~16 KB of static LDS
-    // (the blocked kernel has its own ring depth limit, checked by srk_align_blk_supports: it does not inherit the
-    // level-synchronous kernel's 32-slot limit)
-    // (the blocked kernel wraps its LDS window addresses into 128 KB: static tables + four sequence copies must fit below)
-    if (kblock > 0 && (long long)max_words * 16 + 36 * 1024 <= 128 * 1024) impl = 2;
-    if (const char *e = getenv("SR_ALIGN_IMPL")) {       // (a request for the level-per-pass kernel falls through to kernel 0 when its ring is too shallow)
-        const int want = std::max(0, atoi(e)), bfs_ok = std::max(pen.scope, ori.scope) + 1 <= 32;
-        if (want < impl) impl = (want == 1 && !bfs_ok) ? 0 : want;
-    }
-    if (impl == 0 && sm.bits != 2)
-        return fail(SR_ERR_UNSUPPORTED, "penalties with scope > 31 run on sr_align_kernel, which is built for upper-case ACGT input only");
-    if (impl == 2) c->lds_bytes = (size_t)max_words * 4 * 4 + 16;      // (+ read slack of a two-window extension step)
-    int wg_per_cu = impl ? 4 : 8;
-    if (const char *e = getenv("SR_WG_PER_CU")) wg_per_cu = std::max(1, atoi(e));
-    c->nthreads = impl ? 256 : 128;
+    if (const char *e = getenv("SR_BLK_LEVELS")) { if (atoi(e) == 5 && pl.kblock == 10) pl.kblock = 5; }
+    // (the blocked kernel stages four sequence copies, has ~20 KB of static LDS and keeps its LDS window addresses within
+    // 128 KB: static tables + copies must fit below; it has its own ring depth limit, srk_align_blk_supports)
+    if (pl.kblock > 0 && (long long)pl.max_words * 16 + 28 * 1024 <= 128 * 1024) pl.impl = 2;
+    if (const char *e = getenv("SR_ALIGN_IMPL")) { if (atoi(e) <= 1) pl.impl = 1; }      // (tests: the level-per-pass kernel)
+    int &impl = pl.impl, &kblock = pl.kblock;
+    if (impl == 2) c->lds_bytes = (size_t)pl.max_words * 4 * 4 + 16;      // (+ read slack of a two-window extension step)
+    pl.wg_per_cu = 4;
+    if (const char *e = getenv("SR_WG_PER_CU")) pl.wg_per_cu = std::max(1, atoi(e));
+    c->nthreads = 256;
     // few pairs (e.g. the 1/8 shard of C2): one pair per workgroup leaves CUs short of waves, so give every
     // pair 8 waves instead of 4 (measured 31 -> 23 ms for 529 pairs of 5 kb)
     if (impl == 2 && (uint64_t)np <= 2ULL * (uint64_t)cus + (uint64_t)cus / 2) c->nthreads = 512;
     // fewer pairs than CUs (C3: 144): a pair has a CU to itself -- 16 waves (C3 90.1 -> 69.2 ms)
     if (impl == 2 && (uint64_t)np <= (uint64_t)cus) c->nthreads = 1024;
-    if (const char *e = getenv("SR_ALIGN_THREADS")) { int v = atoi(e); if (impl ? (v == 128 || v == 256 || v == 512 || (v == 1024 && impl == 2) || (v == 64 && impl == 2 && sm.bits == 2)) : (v == 64 || v == 128 || v == 256)) c->nthreads = v; }
-    if (c->nthreads == 1024 && !(impl == 2 && kblock == 10 && c->off16 && sm.bits == 2 && pen.two)) c->nthreads = 512;   // (the one 1024-thread build)
-    if (impl == 2 && c->nthreads == 128 && kblock == 10 && !(sm.bits == 2 && c->off16)) kblock = 5;   // (no 128-thread 10-level instance there)
-    const bool wave_wg = impl == 2 && (c->nthreads == 64 || (c->nthreads == 128 && kblock == 10));   // lean builds: 16 / 8 pairs per CU
-    if (wave_wg) wg_per_cu = c->nthreads == 64 ? 16 : 8;
-    size_t lds_static = (size_t)(wave_wg ? 6 : impl == 2 ? 22 : impl ? 28 : 8) * 1024;      // static tables of the kernel (upper estimate)
+    if (const char *e = getenv("SR_ALIGN_THREADS")) {
+        const int v = atoi(e);
+        if (v == 128 || v == 256 || v == 512 || (v == 1024 && impl == 2) || (v == 64 && impl == 2 && bits == 2)) c->nthreads = v;
+    }
+    if (c->nthreads == 1024 && !(impl == 2 && kblock == 10 && c->off16 && bits == 2 && pen.two)) c->nthreads = 512;   // (the one 1024-thread build)
+    if (impl == 2 && c->nthreads == 128 && kblock == 10 && !(bits == 2 && c->off16)) kblock = 5;   // (no 128-thread 10-level instance there)
+    pl.wave_wg = impl == 2 && (c->nthreads == 64 || (c->nthreads == 128 && kblock == 10));   // lean builds: 16 / 8 pairs per CU
+    if (pl.wave_wg) pl.wg_per_cu = c->nthreads == 64 ? 16 : 8;
+    size_t lds_static = (size_t)(pl.wave_wg ? 6 : impl == 2 ? 22 : 28) * 1024;      // static tables of the kernel (upper estimate)
     if (const char *e = getenv("SR_STATIC_LDS_KB")) lds_static = (size_t)std::max(1, atoi(e)) * 1024;       // (A/B builds with other table sizes)
     const size_t lds_per_wg = c->lds_bytes + lds_static;
-    wg_per_cu = (int)std::min<size_t>((size_t)wg_per_cu, std::max<size_t>(1, (160 * 1024) / lds_per_wg));
+    pl.wg_per_cu = (int)std::min<size_t>((size_t)pl.wg_per_cu, std::max<size_t>(1, (160 * 1024) / lds_per_wg));
     // long sequences: the four LDS copies leave room for two workgroups per CU (C5: 50 KB each) -- give each 8 waves, or
     // the SIMDs hold two waves (C5 subset 3 507 -> 2 200 ms).  512-thread builds: int16 rows; 32-bit searches with the
     // uint16 ring (exact instance below 57 k, see ring_u16)
-    if (impl == 2 && !wave_wg && wg_per_cu <= 2 && !getenv("SR_ALIGN_THREADS")) {
-        const char *ru_ = getenv("SR_RING_U16");
-        if (c->off16 || (kblock == 10 && maxlen <= 57000 && !(ru_ && atoi(ru_) == 0))) c->nthreads = 512;
-    }
-    const int ring_scope = std::max(pen.scope, ori.scope);
-    const int ring_cap = (int)((2 * maxlen + 3 + 7) & ~7ULL);
+    const char *ru = getenv("SR_RING_U16");
+    const bool u16_ok = kblock == 10 && maxlen <= 57000 && !(ru && atoi(ru) == 0);
+    if (impl == 2 && !pl.wave_wg && pl.wg_per_cu <= 2 && !getenv("SR_ALIGN_THREADS") && (c->off16 || u16_ok)) c->nthreads = 512;
+    // 32-bit searches below 57 k keep their ring as uint16 (offset + 8192): half the row bytes (C5 is bound by them).
+    // The exact 10-level instance at >= 256 threads has that build; SR_RING_U16=0 keeps 32-bit rows.
+    pl.ring_u16 = (impl == 2 && !c->off16 && u16_ok && c->nthreads >= 256) ? 1 : 0;
+    pl.rsz = pl.ring_u16 ? 2 : pl.osz;                 // bytes per ring cell (the base-case history keeps osz)
+    pl.bbase_jobs = pl.wave_wg ? (c->nthreads == 64 ? 4 : 8) : 16;
+    if (const char *e = getenv("SR_BFS_BASE_JOBS")) pl.bbase_jobs = std::max(1, std::min(16, atoi(e)));
+    return SR_OK;
+}
+
+// per-workgroup workspace: shared rows (every aligner of a pass owns a sub-range), base-case history, segment lists,
+// reversed op buffers of the base cases, breakpoint candidate list, per-level maxima
+static int plan_workspace(const sr_ctx *c, const SrPen &pen, const SrPen &ori, uint64_t maxlen, Plan &pl) {
+    const int impl = pl.impl, kblock = pl.kblock;
+    pl.ring_scope = std::max(pen.scope, ori.scope);
     int emax = std::max(pen.e1, ori.e1);
     if (pen.two) emax = std::max(emax, pen.e2);
-    const int ring_hot = emax + 2;
-    // M ring | 4 hot I/D rings | cold I/D history | 1 NULL row
-    const uint64_t ring_dir = ((uint64_t)(ring_scope + 1) + 4ULL * ring_hot + 4ULL * (ring_scope + 1) + 1ULL) * (uint64_t)ring_cap;
-    const uint64_t ring_wg = 2ULL * ring_dir;
+    pl.ring_hot = emax + 2;
     const int gapmax = pen.two ? std::max(pen.o1, pen.o2) : pen.o1;
     auto gc = [&](int len) { int g = pen.o1 + pen.e1 * len; if (pen.two) g = std::min(g, pen.o2 + pen.e2 * len); return g; };
+    // worst base case: score <= 250 (+ one gap-open: a half that ends in a gap component) or both lengths <= 100
     const int smax_base = std::max(250 + gapmax, 2 * gc(100)) + 2 * gapmax + 4;
-    const int hist_levels = smax_base + 1 + std::max(kblock, 5);   // + one block of levels (impl 2 computes whole blocks)
+    pl.hist_levels = smax_base + 1 + std::max(kblock, 5);   // + one block of levels (impl 2 computes whole blocks)
     int rmax = smax_base / pen.e1;
     if (pen.two) rmax = std::max(rmax, smax_base / pen.e2);
-    const int hist_w = (2 * (rmax + pen.scope + 2) + 1 + 8 + 64 + 7) & ~7;   // (+ halo groups of the deepest tile either side)   // rows hold whole 4-diagonal groups
-    const uint64_t hist_wg = (uint64_t)hist_levels * 5 * (uint64_t)hist_w + (uint64_t)hist_w;   // + NULL row
-    // bfs kernel workspace: shared rows (every aligner owns a sub-range) + batched base-case history
-    const int brow = (int)((4 * maxlen + 32 * 72 + 64 + 512 + 7) & ~7ULL);     // per-aligner margins + read slack of the last wave tile
-    int kdepth = std::max(pen.scope + std::max(kblock, 1), ori.scope + 1) + 1;
+    pl.hist_w = (2 * (rmax + pen.scope + 2) + 1 + 8 + 64 + 7) & ~7;   // rows hold whole 4-diagonal groups, + halo groups either side
+    pl.brow = (int)((4 * maxlen + 32 * 72 + 64 + 512 + 7) & ~7ULL);     // per-aligner margins + read slack of the last wave tile
+    pl.kdepth = std::max(pen.scope + std::max(kblock, 1), ori.scope + 1) + 1;
     // lazy I/D rows (sr_align_blk.inc blk_recompute): the M rows must reach 2 * scope + 2 blocks back
     const char *lz = getenv("SR_LAZY_ID");
-    const int lazy_id = (impl == 2 && !(lz && atoi(lz) == 0) && 2 * pen.scope + 2 * kblock + 2 <= SR_BLK_MAK_SLOTS) ? 1 : 0;
-    if (lazy_id) kdepth = std::max(kdepth, 2 * pen.scope + 2 * kblock + 2);
-    uint64_t bring_wg = ((uint64_t)(ring_scope + 1) + 4ULL * ring_hot + 4ULL * (ring_scope + 1) + 2ULL) * (uint64_t)brow;   // + NULL row + U row
-    // impl 2: chunk-major ring (sr_align_blk.inc KRows): 256-cell pieces of all 5 * depth + 2 rows together, + 2 pieces of read slack
-    if (impl == 2) bring_wg = ((uint64_t)brow / 256 + 2ULL) * ((uint64_t)kdepth * 5 + 3ULL) * 256ULL + 1024;      // rows: 5 x depth + NULL + U + trash
-    // (the blocked kernel addresses a workgroup's rows as base + 32-bit byte offset)
-    // 32-bit searches below 57 k keep their ring as uint16 (offset + 8192): half the row bytes (C5 is bound by them).
-    // The exact 10-level instance at 256 threads has that build; SR_RING_U16=0 keeps 32-bit rows.
-    const char *ru = getenv("SR_RING_U16");
-    const int ring_u16 = (impl == 2 && !c->off16 && kblock == 10 && c->nthreads >= 256 && maxlen <= 57000 && !(ru && atoi(ru) == 0)) ? 1 : 0;
-    const size_t rsz = ring_u16 ? 2 : osz;                 // bytes per ring cell (the base-case history keeps osz)
-    if (impl == 2 && bring_wg * rsz >= (1ULL << 32)) return fail(SR_ERR_UNSUPPORTED, "sequences too long for the device row workspace (4 GB per workgroup)");
-    int bbase_jobs = wave_wg ? (c->nthreads == 64 ? 4 : 8) : 16;
-    if (const char *e = getenv("SR_BFS_BASE_JOBS")) bbase_jobs = std::max(1, std::min(16, atoi(e)));
-    // base-case history of a workgroup.  Level-per-pass kernel: bbase_jobs fixed slots of the worst-case width.  Blocked
-    // kernel: hist_cap cells that every batch lays out for the levels and widths its jobs really need (sr_align_blk.inc);
-    // one worst-case job always fits, the default holds 5 of them (C2: 13 MB instead of 40.6 -- a pair's 16 base cases of
-    // score ~150 still run as one batch; SR_HIST_JOBS=n: n of them).
-    const uint64_t hist_worst = (uint64_t)hist_levels * 5 * (uint64_t)hist_w;
-    uint64_t hist_cap = hist_worst * 5;
-    if (const char *e = getenv("SR_HIST_JOBS")) hist_cap = hist_worst * (uint64_t)std::max(1, std::min(16, atoi(e)));
-    const uint64_t hist_nul_w = (uint64_t)bbase_jobs * (uint64_t)hist_w;
-    const uint64_t bhist_wg = impl == 2 ? ((hist_cap + hist_nul_w + 256 + 1024 + 7) & ~7ULL)      // data, NULL row, trash cells, slack
-                                        : ((uint64_t)hist_levels * 5 + 1) * (uint64_t)bbase_jobs * (uint64_t)hist_w + 1024;
-    const uint64_t bseg_wg = 2ULL * SR_BFS_MAXSEG * SR_BFS_SEGREC * 4;          // bytes
-    const uint64_t bbt_wg = (uint64_t)bbase_jobs * SR_BFS_BTCAP * 4;           // bytes
-    // impl 2: every diagonal of every level of a block can be a breakpoint candidate at worst
-    const uint64_t bcl_wg = (impl == 2) ? (uint64_t)std::max(kblock, 1) * (uint64_t)brow : 0;
-    const uint64_t per_wg_bytes = impl ? bring_wg * rsz + bhist_wg * osz + bseg_wg + bbt_wg + bcl_wg * 4 + (impl == 2 ? 32 * SR_BLK_MAK_SLOTS * 4 : 0)
-                                       : (ring_wg + hist_wg) * osz;
-    // ---- memory budget: every buffer counted.  fixed = union-find arrays + per-pair arrays;
-    //      then the CIGAR arena (worst case |q|+|t|+2 ops per pair; pairs run in batches that reuse it), the
-    //      orientation rings and the alignment workspaces share what is left.
-    size_t free_b = 0, total_b = 0;
-    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    pl.lazy_id = (impl == 2 && !(lz && atoi(lz) == 0) && 2 * pen.scope + 2 * kblock + 2 <= SR_BLK_MAK_SLOTS) ? 1 : 0;
+    if (pl.lazy_id) pl.kdepth = std::max(pl.kdepth, 2 * pen.scope + 2 * kblock + 2);
+    // level-per-pass kernel: M ring | 4 hot I/D rings | cold I/D history | NULL row | U row, rows of brow cells
+    pl.bring_wg = ((uint64_t)(pl.ring_scope + 1) + 4ULL * pl.ring_hot + 4ULL * (pl.ring_scope + 1) + 2ULL) * (uint64_t)pl.brow;
+    // blocked kernel: chunk-major ring (sr_align_blk.inc KRows): 256-cell pieces of all 5 * depth + 3 rows together
+    // (NULL, U, trash), + 2 pieces of read slack; a workgroup's rows are addressed as base + 32-bit byte offset
+    if (impl == 2) pl.bring_wg = ((uint64_t)pl.brow / 256 + 2ULL) * ((uint64_t)pl.kdepth * 5 + 3ULL) * 256ULL + 1024;
+    if (impl == 2 && pl.bring_wg * pl.rsz >= (1ULL << 32)) return fail(SR_ERR_UNSUPPORTED, "sequences too long for the device row workspace (4 GB per workgroup)");
+    // base-case history.  Level-per-pass kernel: bbase_jobs fixed slots of the worst-case width.  Blocked kernel: hist_cap
+    // cells that every batch lays out for the levels and widths its jobs really need (sr_align_blk.inc); one worst-case
+    // job always fits, the default holds 5 of them (C2: 13 MB instead of 40.6 -- a pair's 16 base cases of score ~150 still
+    // run as one batch; SR_HIST_JOBS=n: n of them)
+    const uint64_t hist_worst = (uint64_t)pl.hist_levels * 5 * (uint64_t)pl.hist_w;
+    pl.hist_cap = hist_worst * 5;
+    if (const char *e = getenv("SR_HIST_JOBS")) pl.hist_cap = hist_worst * (uint64_t)std::max(1, std::min(16, atoi(e)));
+    pl.hist_nul_w = (uint64_t)pl.bbase_jobs * (uint64_t)pl.hist_w;
+    pl.bhist_wg = impl == 2 ? ((pl.hist_cap + pl.hist_nul_w + 256 + 1024 + 7) & ~7ULL)      // data, NULL row, trash cells, slack
+                            : ((uint64_t)pl.hist_levels * 5 + 1) * pl.hist_nul_w + 1024;
+    pl.bseg_wg = 2ULL * SR_BFS_MAXSEG * SR_BFS_SEGREC * 4;          // bytes
+    pl.bbt_wg = (uint64_t)pl.bbase_jobs * SR_BFS_BTCAP * 4;        // bytes
+    pl.bcl_wg = (impl == 2) ? (uint64_t)std::max(kblock, 1) * (uint64_t)pl.brow : 0;      // (kept for the candidate-list variant of breakpoint detection)
+    pl.per_wg_bytes = pl.bring_wg * pl.rsz + pl.bhist_wg * pl.osz + pl.bseg_wg + pl.bbt_wg + pl.bcl_wg * 4 + (impl == 2 ? 32 * SR_BLK_MAK_SLOTS * 4 : 0);
+    (void)c;
+    return SR_OK;
+}
+
+// memory budget: every buffer counted.  fixed = union-find arrays + per-pair arrays; then the CIGAR arena (worst
+// case |q|+|t|+2 ops per pair; pairs run in batches that reuse it), the orientation rings and the alignment workspaces share
+// what is left
+static int plan_memory(sr_ctx *c, uint32_t np, Plan &pl) {
+    size_t total_b = 0;
+    HIPCHK(hipMemGetInfo(&pl.free_b, &total_b));
     const uint64_t fixed = 3ULL * c->uf_size * 8 + (uint64_t)np * 40 + (1ULL << 20);
-    if (fixed + (64ULL << 20) > free_b) return fail(SR_ERR_NOMEM, "not enough device memory for the union-find arrays");
-    const uint64_t avail = free_b - fixed;
-    uint64_t arena_ops = c->cigar_base[np] + 1;
+    if (fixed + (64ULL << 20) > pl.free_b) return fail(SR_ERR_NOMEM, "not enough device memory for the union-find arrays");
+    const uint64_t avail = pl.free_b - fixed;
+    pl.arena_ops = c->cigar_base[np] + 1;
     {
-        uint64_t cap = std::max<uint64_t>((uint64_t)(avail * 0.25) / 4, max_reserve + 1);
-        if (const char *e = getenv("SR_CIGAR_ARENA_OPS")) cap = std::max<uint64_t>((uint64_t)atoll(e), max_reserve + 1);   // (tests: force batches)
-        arena_ops = std::min(arena_ops, cap);
+        uint64_t cap = std::max<uint64_t>((uint64_t)(avail * 0.25) / 4, pl.max_reserve + 1);
+        if (const char *e = getenv("SR_CIGAR_ARENA_OPS")) cap = std::max<uint64_t>((uint64_t)atoll(e), pl.max_reserve + 1);   // (tests: force batches)
+        pl.arena_ops = std::min(pl.arena_ops, cap);
     }
-    if (arena_ops * 4 > avail / 2) return fail(SR_ERR_NOMEM, "not enough device memory for one pair's CIGAR");
+    if (pl.arena_ops * 4 > avail / 2) return fail(SR_ERR_NOMEM, "not enough device memory for one pair's CIGAR");
     c->batch_first.assign(1, 0);
     for (uint32_t i = 0; i < np; i++)
-        if (c->cigar_base[i + 1] - c->cigar_base[c->batch_first.back()] + 1 > arena_ops) c->batch_first.push_back(i);
+        if (c->cigar_base[i + 1] - c->cigar_base[c->batch_first.back()] + 1 > pl.arena_ops) c->batch_first.push_back(i);
     c->batch_first.push_back(np);
-    const uint32_t nbatch = (uint32_t)c->batch_first.size() - 1;
-    uint32_t max_batch_pairs = 0;
-    for (uint32_t b = 0; b < nbatch; b++) max_batch_pairs = std::max(max_batch_pairs, c->batch_first[b + 1] - c->batch_first[b]);
-    const uint64_t left = avail - arena_ops * 4;
-    uint64_t budget = (uint64_t)(left * 0.7);
-    int nwg = cus * wg_per_cu;
+    pl.nbatch = (uint32_t)c->batch_first.size() - 1;
+    pl.max_batch_pairs = 0;
+    for (uint32_t b = 0; b < pl.nbatch; b++) pl.max_batch_pairs = std::max(pl.max_batch_pairs, c->batch_first[b + 1] - c->batch_first[b]);
+    pl.left = avail - pl.arena_ops * 4;
+    const uint64_t budget = (uint64_t)(pl.left * 0.7);
+    int nwg = pl.cus * pl.wg_per_cu;
     if (const char *e = getenv("SR_NWG")) nwg = std::max(1, std::min(nwg, atoi(e)));   // (tests: several pairs per workgroup on a small input)
-    if ((uint64_t)nwg > max_batch_pairs) nwg = (int)max_batch_pairs;
+    if ((uint64_t)nwg > pl.max_batch_pairs) nwg = (int)pl.max_batch_pairs;
     if (nwg < 1) nwg = 1;
-    while (nwg > 1 && (uint64_t)nwg * per_wg_bytes > budget) nwg--;
-    if ((uint64_t)nwg * per_wg_bytes > budget) return fail(SR_ERR_NOMEM, "not enough device memory for one workgroup's wavefront ring");
-    c->nwg = nwg;
-    // ---- per-pair device arrays
+    while (nwg > 1 && (uint64_t)nwg * pl.per_wg_bytes > budget) nwg--;
+    if ((uint64_t)nwg * pl.per_wg_bytes > budget) return fail(SR_ERR_NOMEM, "not enough device memory for one workgroup's wavefront ring");
+    pl.nwg = c->nwg = nwg;
+    return SR_OK;
+}
+
+// per-pair device arrays, workspaces, kernel arguments
+static int alloc_workspace(sr_ctx *c, const sr_params *p, const PackedSeqs &pk, const SeqDev &sd, const SrPen &pen, const SrPen &ori,
+                           uint64_t maxlen, const std::vector<int32_t> &max_score, Plan &pl) {
+    int r;
+    void *d;
+    const uint32_t np = (uint32_t)c->pair_q.size(), nbatch = pl.nbatch;
+    const int impl = pl.impl, nwg = pl.nwg;
+    const size_t osz = pl.osz, rsz = pl.rsz;
+    SrAlignArgs &a = c->aa;
+    memset(&a, 0, sizeof(a));
+    uint32_t *d_pq, *d_pt;
     std::vector<uint32_t> pq = c->pair_q, pt = c->pair_t;
     if (pq.empty()) { pq.push_back(0); pt.push_back(0); }
     DEV_UPLOAD(d_pq, uint32_t, pq);
     DEV_UPLOAD(d_pt, uint32_t, pt);
-    // (cb and order live until the stream synchronisation below: the uploads are asynchronous)
+    // per-batch relative CIGAR bases: batch b owns entries [first_b + b, first_b + b + count_b]
     std::vector<uint64_t> cb((size_t)np + nbatch, 0);
+    for (uint32_t b = 0; b < nbatch; b++) {
+        const uint32_t f = c->batch_first[b], l = c->batch_first[b + 1];
+        for (uint32_t i = f; i <= l; i++) cb[(size_t)i + b] = c->cigar_base[i] - c->cigar_base[f];
+    }
+    DEV_UPLOAD(c->d_cbase, uint64_t, cb);
+    // cost-sorted dequeue order inside each batch: the longest pairs start first (self pairs last)
     std::vector<uint32_t> order(std::max<uint32_t>(np, 1), 0);
-    {   // per-batch relative CIGAR bases: batch b owns entries [first_b + b, first_b + b + count_b]
-        for (uint32_t b = 0; b < nbatch; b++) {
-            const uint32_t f = c->batch_first[b], l = c->batch_first[b + 1];
-            for (uint32_t i = f; i <= l; i++) cb[(size_t)i + b] = c->cigar_base[i] - c->cigar_base[f];
-        }
-        DEV_UPLOAD(c->d_cbase, uint64_t, cb);
+    for (uint32_t b = 0; b < nbatch; b++) {
+        const uint32_t f = c->batch_first[b], l = c->batch_first[b + 1];
+        std::vector<uint32_t> idx(l - f);
+        for (uint32_t i = 0; i < l - f; i++) idx[i] = i;
+        auto cost = [&](uint32_t i) { const uint32_t q = c->pair_q[f + i], t = c->pair_t[f + i];
+                                      return q == t ? (uint64_t)c->len[q] : (uint64_t)c->len[q] * c->len[t]; };
+        std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return cost(x) > cost(y); });
+        for (uint32_t i = 0; i < l - f; i++) order[f + i] = idx[i];
     }
-    {   // cost-sorted dequeue order inside each batch: the longest pairs start first (self pairs last)
-        for (uint32_t b = 0; b < nbatch; b++) {
-            const uint32_t f = c->batch_first[b], l = c->batch_first[b + 1];
-            std::vector<uint32_t> idx(l - f);
-            for (uint32_t i = 0; i < l - f; i++) idx[i] = i;
-            auto cost = [&](uint32_t i) { const uint32_t q = c->pair_q[f + i], t = c->pair_t[f + i];
-                                          return q == t ? (uint64_t)c->len[q] : (uint64_t)c->len[q] * c->len[t]; };
-            std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return cost(x) > cost(y); });
-            for (uint32_t i = 0; i < l - f; i++) order[f + i] = idx[i];
-        }
-        DEV_UPLOAD(c->d_order, uint32_t, order);
-    }
+    DEV_UPLOAD(c->d_order, uint32_t, order);
     DEV_UPLOAD(c->d_max_score, int32_t, max_score);
-    HIPCHK(hipStreamSynchronize(c->stream));   // the uploads above have read their host vectors
+    HIPCHK(hipStreamSynchronize(c->stream));   // the uploads above have read their host vectors (pq, pt, cb, order)
     if ((r = dev_alloc(c, &d, sizeof(uint32_t)))) return r; c->d_queue = (uint32_t *)d;
-    uint64_t oring_bytes = 0;
-    if (impl) {
-        if ((r = dev_alloc(c, &d, (uint64_t)nwg * bring_wg * rsz))) return r; a.bring = d;
-        if ((r = dev_alloc(c, &d, (uint64_t)nwg * bhist_wg * osz))) return r; a.bhist = d;
-        // (tests: the kernels must not depend on what the row workspaces held before -- poison them with plausible offsets)
-        if (const char *e = getenv("SR_POISON_ROWS")) {
-            const int v = atoi(e);
-            if (rsz == 2) HIPCHK(hipMemsetD16Async((hipDeviceptr_t)a.bring, (unsigned short)(ring_u16 ? v + 8192 : v), (size_t)nwg * bring_wg, c->stream));
-            else HIPCHK(hipMemsetD32Async((hipDeviceptr_t)a.bring, v, (size_t)nwg * bring_wg, c->stream));
-            if (osz == 2) HIPCHK(hipMemsetD16Async((hipDeviceptr_t)a.bhist, (unsigned short)v, (size_t)nwg * bhist_wg, c->stream));
-            else HIPCHK(hipMemsetD32Async((hipDeviceptr_t)a.bhist, v, (size_t)nwg * bhist_wg, c->stream));
-        }
-        if ((r = dev_alloc(c, &d, (uint64_t)nwg * bseg_wg))) return r; a.bseg = (int *)d;
-        if ((r = dev_alloc(c, &d, (uint64_t)nwg * bbt_wg))) return r; a.bbt = (uint32_t *)d;
-        if (bcl_wg) { if ((r = dev_alloc(c, &d, (uint64_t)nwg * bcl_wg * 4))) return r; a.bcl = (uint32_t *)d; a.bcl_wg_stride = bcl_wg; }
-        if (impl == 2) { if ((r = dev_alloc(c, &d, (uint64_t)nwg * 32 * SR_BLK_MAK_SLOTS * 4))) return r; a.bmak = (int *)d; }
-        // orientation as its own kernel, one pair per wave (sr_orient.hip); SR_PREORIENT=0 keeps it in the alignment kernel
-        // Worth it when there are enough pairs to fill the chip with one wave each and the three sequence copies of a
-        // wave leave >= 8 waves per CU (measured: C2 / C4 faster; C3 -- 144 pairs -- 1.6x and C5 -- 50 kb, 4 waves per
-        // CU by LDS -- 9 % slower than orientation inside the alignment kernel's workgroup).  SR_PREORIENT=1 / 0 forces.
-        const char *po = getenv("SR_PREORIENT");
-        const bool pre_auto = (uint64_t)np >= 4ULL * (uint64_t)cus && (size_t)max_words * 12 <= 20 * 1024;
-        if (impl == 2 && (po ? atoi(po) != 0 : pre_auto) && (size_t)max_words * 12 <= 60 * 1024) {
-            const int orow = (int)((2 * ((2 * maxlen + 32) & ~3ULL) + 512 + 7) & ~7ULL);
-            const uint64_t oring_wg = ((uint64_t)(ori.scope + 1) * 3 + 1) * (uint64_t)orow + 256;
-            int onwg = (int)std::min<uint64_t>(max_batch_pairs, (uint64_t)cus * 16);
-            while (onwg > 1 && (uint64_t)onwg * oring_wg * osz > (uint64_t)(left * 0.2)) onwg--;
-            if (onwg >= 1 && np > 0) {
-                oring_bytes = (uint64_t)onwg * oring_wg * osz;
-                if ((r = dev_alloc(c, &d, oring_bytes))) return r; a.oring = d;
-                if ((r = dev_alloc(c, &d, sizeof(uint32_t)))) return r; c->d_oqueue = (uint32_t *)d;
-                a.oring_wg_stride = oring_wg; a.orow = orow; a.oqueue = c->d_oqueue; a.pre_oriented = 1;
-                if (!getenv("SR_NO_REORDER")) {       // dequeue order from the orientation scores, per batch
-                    c->otemp_bytes = srk_order_temp_bytes(max_batch_pairs);
-                    if ((r = dev_alloc(c, &d, (uint64_t)max_batch_pairs * 8))) return r; c->d_okeys = (uint64_t *)d;
-                    if ((r = dev_alloc(c, &d, (uint64_t)max_batch_pairs * 8))) return r; c->d_okeys2 = (uint64_t *)d;
-                    if ((r = dev_alloc(c, &d, (uint64_t)max_batch_pairs * 4))) return r; c->d_ovals = (uint32_t *)d;
-                    if ((r = dev_alloc(c, &d, std::max<size_t>(c->otemp_bytes, 16)))) return r; c->d_otemp = d;
-                }
-                c->onwg = onwg; c->olds_bytes = (size_t)max_words * 3 * 4;
+    if ((r = dev_alloc(c, &d, (uint64_t)nwg * pl.bring_wg * rsz))) return r; a.bring = d;
+    if ((r = dev_alloc(c, &d, (uint64_t)nwg * pl.bhist_wg * osz))) return r; a.bhist = d;
+    // (tests: the kernels must not depend on what the row workspaces held before -- poison them with plausible offsets)
+    if (const char *e = getenv("SR_POISON_ROWS")) {
+        const int v = atoi(e);
+        if (rsz == 2) HIPCHK(hipMemsetD16Async((hipDeviceptr_t)a.bring, (unsigned short)(pl.ring_u16 ? v + 8192 : v), (size_t)nwg * pl.bring_wg, c->stream));
+        else HIPCHK(hipMemsetD32Async((hipDeviceptr_t)a.bring, v, (size_t)nwg * pl.bring_wg, c->stream));
+        if (osz == 2) HIPCHK(hipMemsetD16Async((hipDeviceptr_t)a.bhist, (unsigned short)v, (size_t)nwg * pl.bhist_wg, c->stream));
+        else HIPCHK(hipMemsetD32Async((hipDeviceptr_t)a.bhist, v, (size_t)nwg * pl.bhist_wg, c->stream));
+    }
+    if ((r = dev_alloc(c, &d, (uint64_t)nwg * pl.bseg_wg))) return r; a.bseg = (int *)d;
+    if ((r = dev_alloc(c, &d, (uint64_t)nwg * pl.bbt_wg))) return r; a.bbt = (uint32_t *)d;
+    if (pl.bcl_wg) { if ((r = dev_alloc(c, &d, (uint64_t)nwg * pl.bcl_wg * 4))) return r; a.bcl = (uint32_t *)d; a.bcl_wg_stride = pl.bcl_wg; }
+    if (impl == 2) { if ((r = dev_alloc(c, &d, (uint64_t)nwg * 32 * SR_BLK_MAK_SLOTS * 4))) return r; a.bmak = (int *)d; }
+    // orientation as its own kernel, one pair per wave (sr_orient.hip); SR_PREORIENT=0 keeps it in the alignment kernel.
+    // Worth it when there are enough pairs to fill the chip with one wave each and the three sequence copies of a
+    // wave leave >= 8 waves per CU (measured: C2 / C4 faster; C3 -- 144 pairs -- 1.6x and C5 -- 50 kb, 4 waves per
+    // CU by LDS -- 9 % slower than orientation inside the alignment kernel's workgroup).  SR_PREORIENT=1 / 0 forces.
+    const char *po = getenv("SR_PREORIENT");
+    const bool pre_auto = (uint64_t)np >= 4ULL * (uint64_t)pl.cus && (size_t)pl.max_words * 12 <= 20 * 1024;
+    if (impl == 2 && (po ? atoi(po) != 0 : pre_auto) && (size_t)pl.max_words * 12 <= 60 * 1024) {
+        const int orow = (int)((2 * ((2 * maxlen + 32) & ~3ULL) + 512 + 7) & ~7ULL);
+        const uint64_t oring_wg = ((uint64_t)(ori.scope + 1) * 3 + 1) * (uint64_t)orow + 256;
+        int onwg = (int)std::min<uint64_t>(pl.max_batch_pairs, (uint64_t)pl.cus * 16);
+        while (onwg > 1 && (uint64_t)onwg * oring_wg * osz > (uint64_t)(pl.left * 0.2)) onwg--;
+        if (onwg >= 1 && np > 0) {
+            pl.oring_bytes = (uint64_t)onwg * oring_wg * osz;
+            if ((r = dev_alloc(c, &d, pl.oring_bytes))) return r; a.oring = d;
+            if ((r = dev_alloc(c, &d, sizeof(uint32_t)))) return r; c->d_oqueue = (uint32_t *)d;
+            a.oring_wg_stride = oring_wg; a.orow = orow; a.oqueue = c->d_oqueue; a.pre_oriented = 1;
+            if (!getenv("SR_NO_REORDER")) {       // dequeue order from the orientation scores, per batch
+                c->otemp_bytes = srk_order_temp_bytes(pl.max_batch_pairs);
+                if ((r = dev_alloc(c, &d, (uint64_t)pl.max_batch_pairs * 8))) return r; c->d_okeys = (uint64_t *)d;
+                if ((r = dev_alloc(c, &d, (uint64_t)pl.max_batch_pairs * 8))) return r; c->d_okeys2 = (uint64_t *)d;
+                if ((r = dev_alloc(c, &d, (uint64_t)pl.max_batch_pairs * 4))) return r; c->d_ovals = (uint32_t *)d;
+                if ((r = dev_alloc(c, &d, std::max<size_t>(c->otemp_bytes, 16)))) return r; c->d_otemp = d;
             }
+            c->onwg = onwg; c->olds_bytes = (size_t)pl.max_words * 3 * 4;
         }
-    } else {
-        if ((r = dev_alloc(c, &d, (uint64_t)nwg * ring_wg * osz))) return r; a.ring = d;
-        if ((r = dev_alloc(c, &d, (uint64_t)nwg * hist_wg * osz))) return r; a.hist = d;
     }
     if ((r = dev_alloc(c, &d, (size_t)np + 1))) return r; a.is_reverse = (uint8_t *)d;
     if ((r = dev_alloc(c, &d, ((size_t)np + 1) * 4))) return r; a.score = (int32_t *)d;
     if ((r = dev_alloc(c, &d, ((size_t)np + 1) * 4))) return r; a.ori_fwd = (int32_t *)d;
     if ((r = dev_alloc(c, &d, ((size_t)np + 1) * 4))) return r; a.ori_rev = (int32_t *)d;
     if ((r = dev_alloc(c, &d, ((size_t)np + 1) * 4))) return r; a.cigar_cnt = (uint32_t *)d;
-    if ((r = dev_alloc(c, &d, (arena_ops + 1) * 4))) return r; a.cigar_ops = (uint32_t *)d;
+    if ((r = dev_alloc(c, &d, (pl.arena_ops + 1) * 4))) return r; a.cigar_ops = (uint32_t *)d;
     if ((r = dev_alloc(c, &d, SR_NCOUNTERS * sizeof(unsigned long long)))) return r; c->d_counters = (unsigned long long *)d;
     if ((r = dev_alloc(c, &d, sizeof(int)))) return r; c->d_error = (int *)d;
     if ((r = dev_alloc(c, &d, c->uf_size * 8))) return r; c->d_nodes = (unsigned long long *)d;
@@ -794,44 +844,76 @@ static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const
     HIPCHK(hipMemsetAsync(c->d_error, 0, sizeof(int), c->stream));
     HIPCHK(hipMemsetAsync(a.cigar_cnt, 0, ((size_t)np + 1) * 4, c->stream));
     HIPCHK(hipMemsetAsync(a.score, 0xff, ((size_t)np + 1) * 4, c->stream));
-    a.seqwords = d_words; a.word_off_fwd = d_w[0]; a.word_off_rc = d_w[1]; a.word_off_rev = d_w[2]; a.word_off_cmp = d_w[3];
-    a.symbits = sm.bits; a.order = c->d_order; a.seqlen = d_len;
-    a.max_words = max_words; a.pair_q = d_pq; a.pair_t = d_pt; a.npairs = np;
+    a.seqwords = sd.words; a.word_off_fwd = sd.woff[0]; a.word_off_rc = sd.woff[1]; a.word_off_rev = sd.woff[2]; a.word_off_cmp = sd.woff[3];
+    a.symbits = pk.sm.bits; a.order = c->d_order; a.seqlen = sd.len;
+    a.max_words = pl.max_words; a.pair_q = d_pq; a.pair_t = d_pt; a.npairs = np;
     a.queue_head = c->d_queue; a.pen = pen; a.ori = ori; a.mem_mode = p->memory_mode;
-    a.ring_wg_stride = ring_wg; a.ring_dir_stride = ring_dir; a.ring_cap = ring_cap; a.ring_scope = ring_scope; a.ring_hot = ring_hot;
-    a.hist_wg_stride = hist_wg; a.hist_w = hist_w; a.hist_levels = hist_levels;
+    a.ring_scope = pl.ring_scope; a.ring_hot = pl.ring_hot;
+    a.hist_w = pl.hist_w; a.hist_levels = pl.hist_levels;
     { const char *pt_ = getenv("SR_PROFILE_TICKS"); a.profile_ticks = (pt_ && atoi(pt_) != 0) ? 1 : 0; }
-    a.impl = impl; a.kdepth = kdepth; a.kblock = kblock; a.lazy_id = lazy_id; a.ring_u16 = ring_u16; a.ori_levels = getenv("SR_ORIENT_LEVELS") ? 1 : 0; a.bring_wg_stride = bring_wg; a.brow = brow; a.bhist_wg_stride = bhist_wg; a.bbase_jobs = bbase_jobs;
-    a.hist_cap = hist_cap; a.hist_nul_w = (uint32_t)hist_nul_w; a.hist_stride = (uint32_t)hist_nul_w;
+    a.impl = impl; a.kdepth = pl.kdepth; a.kblock = pl.kblock; a.lazy_id = pl.lazy_id; a.ring_u16 = pl.ring_u16;
+    a.ori_levels = getenv("SR_ORIENT_LEVELS") ? 1 : 0;
+    a.bring_wg_stride = pl.bring_wg; a.brow = pl.brow; a.bhist_wg_stride = pl.bhist_wg; a.bbase_jobs = pl.bbase_jobs;
+    a.hist_cap = pl.hist_cap; a.hist_nul_w = (uint32_t)pl.hist_nul_w; a.hist_stride = (uint32_t)pl.hist_nul_w;
     a.cigar_base = c->d_cbase; a.counters = c->d_counters; a.error_flag = c->d_error;
     SrUniteArgs &u = c->ua;
     memset(&u, 0, sizeof(u));
-    u.pair_q = d_pq; u.pair_t = d_pt; u.npairs = np; u.seqlen = d_len; u.seq_goff = d_goff;
+    u.pair_q = d_pq; u.pair_t = d_pt; u.npairs = np; u.seqlen = sd.len; u.seq_goff = sd.goff;
     u.is_reverse = a.is_reverse; u.score = a.score; u.max_score = c->d_max_score;
     u.cigar_ops = a.cigar_ops; u.cigar_base = c->d_cbase; u.cigar_cnt = a.cigar_cnt;
     u.min_match_len = p->min_match_len; u.nodes = c->d_nodes; u.uf_size = c->uf_size;
     u.counters = c->d_counters; u.error_flag = c->d_error;
-    {
-        char buf[800];
-        snprintf(buf, sizeof(buf),
-                 "{\"pairs\": %u, \"batches\": %u, \"symbol_bits\": %d, \"offset_bytes\": %zu, \"ring_cell_bytes\": %zu, \"kernel_impl\": %d, "
-                 "\"block_levels\": %d, \"two_piece\": %d, \"lazy_id_rows\": %d, \"workgroups\": %d, "
-                 "\"threads_per_workgroup\": %d, \"workgroups_per_cu\": %d, \"lds_dynamic_bytes\": %zu, \"ring_bytes_per_workgroup\": %llu, "
-                 "\"base_history_bytes_per_workgroup\": %llu, \"workspace_bytes\": %llu, \"cigar_arena_bytes\": %llu, "
-                 "\"orientation_ring_bytes\": %llu, \"union_find_bytes\": %llu, \"device_free_bytes_at_load\": %zu}",
-                 np, nbatch, sm.bits, osz, impl == 2 ? rsz : osz, impl, impl == 2 ? kblock : 1, pen.two ? 1 : 0, lazy_id, nwg, c->nthreads, wg_per_cu, c->lds_bytes,
-                 (unsigned long long)(impl ? bring_wg * rsz : ring_wg * osz), (unsigned long long)((impl ? bhist_wg : hist_wg) * osz),
-                 (unsigned long long)((uint64_t)nwg * per_wg_bytes), (unsigned long long)(arena_ops * 4), (unsigned long long)oring_bytes,
-                 (unsigned long long)(3ULL * c->uf_size * 8), free_b);
-        c->workspace_report = buf;
-    }
-    int rr = srk_uf_init(c->d_nodes, c->total_len, c->uf_size, c->stream);
-    if (rr) return fail(SR_ERR_HIP, "uf init launch failed");
+    return SR_OK;
+}
+
+static void write_report(sr_ctx *c, const PackedSeqs &pk, const SrPen &pen, const Plan &pl) {
+    const uint32_t np = (uint32_t)c->pair_q.size();
+    char buf[900];
+    snprintf(buf, sizeof(buf),
+             "{\"pairs\": %u, \"batches\": %u, \"symbol_bits\": %d, \"offset_bytes\": %zu, \"ring_cell_bytes\": %zu, \"kernel_impl\": %d, "
+             "\"block_levels\": %d, \"two_piece\": %d, \"lazy_id_rows\": %d, \"workgroups\": %d, "
+             "\"threads_per_workgroup\": %d, \"workgroups_per_cu\": %d, \"lds_dynamic_bytes\": %zu, \"ring_bytes_per_workgroup\": %llu, "
+             "\"base_history_bytes_per_workgroup\": %llu, \"workspace_bytes\": %llu, \"cigar_arena_bytes\": %llu, "
+             "\"orientation_ring_bytes\": %llu, \"union_find_bytes\": %llu, \"device_free_bytes_at_load\": %zu}",
+             np, pl.nbatch, pk.sm.bits, pl.osz, pl.impl == 2 ? pl.rsz : pl.osz, pl.impl, pl.impl == 2 ? pl.kblock : 1, pen.two ? 1 : 0, pl.lazy_id,
+             pl.nwg, c->nthreads, pl.wg_per_cu, c->lds_bytes,
+             (unsigned long long)(pl.bring_wg * pl.rsz), (unsigned long long)(pl.bhist_wg * pl.osz),
+             (unsigned long long)((uint64_t)pl.nwg * pl.per_wg_bytes), (unsigned long long)(pl.arena_ops * 4), (unsigned long long)pl.oring_bytes,
+             (unsigned long long)(3ULL * c->uf_size * 8), pl.free_b);
+    c->workspace_report = buf;
+}
+
+static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const uint32_t *eq, const uint32_t *et,
+                     uint64_t ecount, bool explicit_pairs) {
+    if (!c || !seqs || !p) return fail(SR_ERR_INVALID, "null argument");
+    if (seqs->n == 0) return fail(SR_ERR_INVALID, "no sequences");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    free_dev(c);
+    int r;
+    SrPen pen, ori;
+    uint64_t maxlen = 0;
+    if ((r = load_index(c, seqs, p, explicit_pairs, &pen, &ori, &maxlen))) return r;
+    PackedSeqs pk;
+    pack_sequences(c, seqs, pk);
+    c->symbits = pk.sm.bits;
+    SeqDev sd;
+    if ((r = upload_sequences(c, seqs, pk, sd))) return r;
+    Plan pl;
+    std::vector<int32_t> max_score;
+    if ((r = build_pair_list(c, p, sd, eq, et, ecount, explicit_pairs, max_score, &pl.max_reserve))) return r;
+    const uint32_t np = (uint32_t)c->pair_q.size();
+    if ((r = plan_kernel(c, pk, pen, ori, maxlen, np, pl))) return r;
+    if ((r = plan_workspace(c, pen, ori, maxlen, pl))) return r;
+    if ((r = plan_memory(c, np, pl))) return r;
+    if ((r = alloc_workspace(c, p, pk, sd, pen, ori, maxlen, max_score, pl))) return r;
+    write_report(c, pk, pen, pl);
+    if (srk_uf_init(c->d_nodes, c->total_len, c->uf_size, c->stream)) return fail(SR_ERR_HIP, "uf init launch failed");
     HIPCHK(hipStreamSynchronize(c->stream));
     c->loaded = true;
     return SR_OK;
-#undef DEV_UPLOAD
 }
+#undef DEV_UPLOAD
 
 extern "C" int sr_ctx_load(sr_ctx *c, const sr_seqset *seqs, const sr_params *p) {
     return load_impl(c, seqs, p, nullptr, nullptr, 0, false);
@@ -1009,7 +1091,7 @@ extern "C" uint64_t sr_ctx_dp_cells(const sr_ctx *c) { return c ? c->dp_cells : 
 
 extern "C" const char *sr_ctx_align_kernel(const sr_ctx *c) {
     if (!c || !c->loaded || c->from_paf) return nullptr;
-    return c->aa.impl == 2 ? "sr_align_blk_kernel" : c->aa.impl == 1 ? "sr_align_bfs_kernel" : "sr_align_kernel";
+    return c->aa.impl == 2 ? "sr_align_blk_kernel" : "sr_align_bfs_kernel";
 }
 
 extern "C" int sr_ctx_kernel_ms(sr_ctx *c, int which, float *ms) {

@@ -55,19 +55,12 @@ struct SrAlignArgs {
     SrPen pen, ori;
     int mem_mode;
     // per-workgroup workspace
-    void *ring;                // per WG: 2 directions x { M[(ring_scope+1)] | I1 I2 D1 D2 hot [ring_hot] each |
-                               //   cold I/D history [(ring_scope+1)][4] } rows of ring_cap offsets
-    uint64_t ring_wg_stride;   // elements per workgroup
-    uint64_t ring_dir_stride;  // elements per direction
-    int ring_cap;
     int ring_scope;            // max scope over both penalty sets
-    int ring_hot;              // hot I/D rows per component (max gap-extend + 2)
-    void *hist;                // [nwg][hist_levels][5][hist_w]
-    uint64_t hist_wg_stride;
-    int hist_w, hist_levels;
+    int ring_hot;              // hot I/D rows per component of the level-per-pass kernel's ring (max gap-extend + 2)
+    int hist_w, hist_levels;   // a worst-case base case: history columns, levels
     // level-synchronous ("bfs") kernel workspace, per workgroup
-    int impl;                  // 0 = one segment at a time (sr_align_kernel), 1 = sr_align_bfs_kernel,
-                               // 2 = sr_align_blk_kernel (rows: [kdepth][5 components] | NULL row | U row)
+    int impl;                  // 1 = sr_align_bfs_kernel (level per pass), 2 = sr_align_blk_kernel (score-blocked wave tiles;
+                               // rows: [kdepth][5 components] | NULL row | U row | trash row)
     int kdepth;                // ring depth of impl 2 (scope + levels per block + 1)
     int kblock;                // impl 2: score levels per block (5: generic instance, 10: exact-penalty instance)
     void *bring;               // rows of brow offsets: M[(ring_scope+1)] | hot I1 I2 D1 D2 [ring_hot] each |

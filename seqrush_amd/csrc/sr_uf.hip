@@ -226,8 +226,10 @@ __global__ void sr_merge_kernel(unsigned long long *nodes, unsigned long long n,
     extern "C" int name##_s4(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, int nthreads, void *stream);     \
     extern "C" int name##_s8(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, int nthreads, void *stream);
 SRK_DECL_ALIGN(srk_align_bfs)
+SRK_DECL_ALIGN(srk_align_bfs_wide)
 SRK_DECL_ALIGN(srk_align_blk)
-extern "C" int srk_align_v3(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, int nthreads, void *stream);
+// dynamic LDS a kernel may ask for: the CU's 160 KB minus the largest static tables of any alignment kernel
+extern "C" int srk_align_max_lds(void) { return 160 * 1024 - 30 * 1024; }
 extern "C" int srk_orient_s2(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, void *stream);
 extern "C" int srk_orient_s4(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, void *stream);
 extern "C" int srk_orient_s8(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, void *stream);
@@ -243,13 +245,17 @@ extern "C" int srk_align(const SrAlignArgs *a, int nwg, size_t lds_bytes, int of
         if (a->symbits == 4) return srk_align_blk_s4(a, nwg, lds_bytes, off16, nthreads, stream);
         return srk_align_blk_s2(a, nwg, lds_bytes, off16, nthreads, stream);
     }
+    if (a->impl == 1 && a->ring_scope + 1 > 32) {              // rings deeper than 32 levels: the wide instance
+        if (a->symbits == 8) return srk_align_bfs_wide_s8(a, nwg, lds_bytes, off16, nthreads, stream);
+        if (a->symbits == 4) return srk_align_bfs_wide_s4(a, nwg, lds_bytes, off16, nthreads, stream);
+        return srk_align_bfs_wide_s2(a, nwg, lds_bytes, off16, nthreads, stream);
+    }
     if (a->impl == 1) {
         if (a->symbits == 8) return srk_align_bfs_s8(a, nwg, lds_bytes, off16, nthreads, stream);
         if (a->symbits == 4) return srk_align_bfs_s4(a, nwg, lds_bytes, off16, nthreads, stream);
         return srk_align_bfs_s2(a, nwg, lds_bytes, off16, nthreads, stream);
     }
-    if (a->symbits != 2) return (int)hipErrorInvalidValue;     // sr_align_kernel is built for 2-bit buffers only (host checks)
-    return srk_align_v3(a, nwg, lds_bytes, off16, nthreads, stream);
+    return (int)hipErrorInvalidValue;
 }
 extern "C" int srk_orient(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, void *stream) {
     if (a->symbits == 8) return srk_orient_s8(a, nwg, lds_bytes, off16, stream);

@@ -506,15 +506,15 @@ def test_run_seqrush_cli_end_to_end(gpu, tmp_path, capsys):
     assert main(["-s", str(empty), "-o", str(out), "--no-sort", "--no-compact"]) == 1
 
 
-KERNELS = {"0": "sr_align_kernel", "1": "sr_align_bfs_kernel", "2": "sr_align_blk_kernel"}
+KERNELS = {"1": "sr_align_bfs_kernel", "2": "sr_align_blk_kernel"}
 
 
-@pytest.mark.parametrize("impl,threads", [("0", "128"), ("0", "256"), ("1", "128"), ("1", "512"),
+@pytest.mark.parametrize("impl,threads", [("1", "128"), ("1", "256"), ("1", "512"),
                                           ("2", "64"), ("2", "128"), ("2", "256"), ("2", "512")])
 def test_all_align_kernels_and_workgroup_sizes(gpu, impl, threads, monkeypatch):
-    """sr_align_kernel (one segment at a time, SR_ALIGN_IMPL=0), sr_align_bfs_kernel (level-synchronous, =1)
-    and sr_align_blk_kernel (score-blocked wave tiles, default) implement the same rules: each must match
-    the oracle bit for bit, at every workgroup size"""
+    """sr_align_bfs_kernel (level-synchronous, SR_ALIGN_IMPL=1) and sr_align_blk_kernel (score-blocked wave tiles,
+    default) implement the same rules: each must match the oracle bit for bit, at every workgroup size
+    (round 3: sr_align_kernel, the one-segment-at-a-time kernel of round 1, is retired)"""
     monkeypatch.setenv("SR_ALIGN_IMPL", impl)
     monkeypatch.setenv("SR_ALIGN_THREADS", threads)
     _, _, cnt = check_parity(synth.indel_family(4, 1500, 0.04, 0.015, 131))
@@ -577,6 +577,18 @@ def test_randomised_small_sets(gpu, seed):
     ss = SeqSet(recs); ctx = Context(0); ctx.load(ss, Params(min_match_len=k)); ctx.align(); ctx.unite(); ctx.sync()
     dev = ctx.build_gfa(); ctx.close()
     assert dev == build_gfa(ss, labels)
+
+
+@pytest.mark.parametrize("scores", ["0,3,40,1", "0,4,6,2,45,3", "0,7,100,1"])
+def test_deep_ring_penalties_run_on_the_wide_level_kernel(gpu, scores):
+    """penalty sets whose ring is deeper than 32 levels (a gap piece that opens at 40, 48 or 101) have no blocked
+    instance and exceed the level-per-pass kernel's 32 slots: its wide instance (128 slots, 8 segments per pass) runs
+    them -- for every alphabet (round 2: sr_align_kernel, ACGT only).  CIGARs, strands, scores, partition, GFA vs the oracle"""
+    recs = synth.indel_family(3, 900, 0.05, 0.02, 1411)
+    _, _, cnt = check_parity(recs, scores=scores)
+    assert cnt["align_kernel"] == "sr_align_bfs_kernel"
+    masked = [(n, s[:200] + b"NNNN" + s[204:500].lower() + s[500:]) for n, s in recs]       # 4-bit / raw-byte buffers
+    check_parity(masked, scores=scores)
 
 
 def test_penalties_without_blocked_instance_fall_back(gpu):
