@@ -452,7 +452,7 @@ struct Plan {
     uint32_t max_words = 0;
     size_t osz = 2, rsz = 2;
     // per-workgroup workspace (cells unless stated)
-    int ring_scope = 0, ring_hot = 0, hist_levels = 0, hist_w = 0, brow = 0, kdepth = 0;
+    int ring_scope = 0, ring_hot = 0, hist_levels = 0, hist_w = 0, brow = 0, kdepth = 0, kdepth2 = 0;
     uint64_t bring_wg = 0, bhist_wg = 0, hist_cap = 0, hist_nul_w = 0, bseg_wg = 0, bbt_wg = 0, bcl_wg = 0, per_wg_bytes = 0;
     // memory budget
     size_t free_b = 0;
@@ -692,26 +692,32 @@ static int plan_workspace(const sr_ctx *c, const SrPen &pen, const SrPen &ori, u
     // lazy I/D rows (sr_align_blk.inc blk_recompute): the M rows must reach 2 * scope + 2 blocks back
     const char *lz = getenv("SR_LAZY_ID");
     pl.lazy_id = (impl == 2 && !(lz && atoi(lz) == 0) && 2 * pen.scope + 2 * kblock + 2 <= SR_BLK_MAK_SLOTS) ? 1 : 0;
-    if (pl.lazy_id) pl.kdepth = std::max(pl.kdepth, 2 * pen.scope + 2 * kblock + 2);
+    pl.kdepth2 = pl.kdepth;
+    if (pl.lazy_id) {
+        // I / D rows are read by breakpoint detection (scope levels back from the newest block) and written by the recompute
+        // pass from the block boundary before that window: scope + 2 blocks + 2 levels are live at most
+        pl.kdepth2 = std::max(pl.kdepth, pen.scope + 2 * kblock + 2);
+        pl.kdepth = std::max(pl.kdepth, 2 * pen.scope + 2 * kblock + 2);
+    }
     // level-per-pass kernel: M ring | 4 hot I/D rings | cold I/D history | NULL row | U row, rows of brow cells
     pl.bring_wg = ((uint64_t)(pl.ring_scope + 1) + 4ULL * pl.ring_hot + 4ULL * (pl.ring_scope + 1) + 2ULL) * (uint64_t)pl.brow;
-    // blocked kernel: chunk-major ring (sr_align_blk.inc KRows): 256-cell pieces of all 5 * depth + 3 rows together
+    // blocked kernel: chunk-major ring (sr_align_blk.inc KRows): 256-cell pieces of all depth + 4 * depth2 + 3 rows together
     // (NULL, U, trash), + 2 pieces of read slack; a workgroup's rows are addressed as base + 32-bit byte offset
-    if (impl == 2) pl.bring_wg = ((uint64_t)pl.brow / 256 + 2ULL) * ((uint64_t)pl.kdepth * 5 + 3ULL) * 256ULL + 1024;
+    if (impl == 2) pl.bring_wg = ((uint64_t)pl.brow / 256 + 2ULL) * ((uint64_t)pl.kdepth + 4ULL * pl.kdepth2 + 3ULL) * 256ULL + 1024;
     if (impl == 2 && pl.bring_wg * pl.rsz >= (1ULL << 32)) return fail(SR_ERR_UNSUPPORTED, "sequences too long for the device row workspace (4 GB per workgroup)");
     // base-case history.  Level-per-pass kernel: bbase_jobs fixed slots of the worst-case width.  Blocked kernel: hist_cap
-    // cells that every batch lays out for the levels and widths its jobs really need (sr_align_blk.inc); one worst-case
-    // job always fits, the default holds 5 of them (C2: 13 MB instead of 40.6 -- a pair's 16 base cases of score ~150 still
-    // run as one batch; SR_HIST_JOBS=n: n of them)
+    // cells in which every job of a batch gets a region for the levels and width it really needs (sr_align_blk.inc); one
+    // worst-case job always fits, the default holds 4 of them (C2: 11 MB instead of 40.6 -- a pair's 16 base cases of score
+    // ~150 need 6.5 M cells and still run as one batch; SR_HIST_JOBS=n: n of them)
     const uint64_t hist_worst = (uint64_t)pl.hist_levels * 5 * (uint64_t)pl.hist_w;
-    pl.hist_cap = hist_worst * 5;
+    pl.hist_cap = hist_worst * 4;
     if (const char *e = getenv("SR_HIST_JOBS")) pl.hist_cap = hist_worst * (uint64_t)std::max(1, std::min(16, atoi(e)));
-    pl.hist_nul_w = (uint64_t)pl.bbase_jobs * (uint64_t)pl.hist_w;
+    pl.hist_nul_w = impl == 2 ? (uint64_t)pl.hist_w + 256 : (uint64_t)pl.bbase_jobs * (uint64_t)pl.hist_w;
     pl.bhist_wg = impl == 2 ? ((pl.hist_cap + pl.hist_nul_w + 256 + 1024 + 7) & ~7ULL)      // data, NULL row, trash cells, slack
                             : ((uint64_t)pl.hist_levels * 5 + 1) * pl.hist_nul_w + 1024;
     pl.bseg_wg = 2ULL * SR_BFS_MAXSEG * SR_BFS_SEGREC * 4;          // bytes
     pl.bbt_wg = (uint64_t)pl.bbase_jobs * SR_BFS_BTCAP * 4;        // bytes
-    pl.bcl_wg = (impl == 2) ? (uint64_t)std::max(kblock, 1) * (uint64_t)pl.brow : 0;      // (kept for the candidate-list variant of breakpoint detection)
+    pl.bcl_wg = 0;                 // (round 3: breakpoint detection keeps a band per unit in LDS instead of a candidate list in global memory)
     pl.per_wg_bytes = pl.bring_wg * pl.rsz + pl.bhist_wg * pl.osz + pl.bseg_wg + pl.bbt_wg + pl.bcl_wg * 4 + (impl == 2 ? 32 * SR_BLK_MAK_SLOTS * 4 : 0);
     (void)c;
     return SR_OK;
@@ -851,10 +857,10 @@ static int alloc_workspace(sr_ctx *c, const sr_params *p, const PackedSeqs &pk, 
     a.ring_scope = pl.ring_scope; a.ring_hot = pl.ring_hot;
     a.hist_w = pl.hist_w; a.hist_levels = pl.hist_levels;
     { const char *pt_ = getenv("SR_PROFILE_TICKS"); a.profile_ticks = (pt_ && atoi(pt_) != 0) ? 1 : 0; }
-    a.impl = impl; a.kdepth = pl.kdepth; a.kblock = pl.kblock; a.lazy_id = pl.lazy_id; a.ring_u16 = pl.ring_u16;
+    a.impl = impl; a.kdepth = pl.kdepth; a.kdepth2 = pl.kdepth2; a.kblock = pl.kblock; a.lazy_id = pl.lazy_id; a.ring_u16 = pl.ring_u16;
     a.ori_levels = getenv("SR_ORIENT_LEVELS") ? 1 : 0;
     a.bring_wg_stride = pl.bring_wg; a.brow = pl.brow; a.bhist_wg_stride = pl.bhist_wg; a.bbase_jobs = pl.bbase_jobs;
-    a.hist_cap = pl.hist_cap; a.hist_nul_w = (uint32_t)pl.hist_nul_w; a.hist_stride = (uint32_t)pl.hist_nul_w;
+    a.hist_cap = pl.hist_cap; a.hist_nul_w = (uint32_t)pl.hist_nul_w; a.hist_stride = (uint32_t)((uint64_t)pl.bbase_jobs * (uint64_t)pl.hist_w);
     a.cigar_base = c->d_cbase; a.counters = c->d_counters; a.error_flag = c->d_error;
     SrUniteArgs &u = c->ua;
     memset(&u, 0, sizeof(u));

@@ -61,18 +61,19 @@ struct SrAlignArgs {
     // level-synchronous ("bfs") kernel workspace, per workgroup
     int impl;                  // 1 = sr_align_bfs_kernel (level per pass), 2 = sr_align_blk_kernel (score-blocked wave tiles;
                                // rows: [kdepth][5 components] | NULL row | U row | trash row)
-    int kdepth;                // ring depth of impl 2 (scope + levels per block + 1)
+    int kdepth;                // impl 2: ring depth of the M rows (scope + levels per block + 1; lazy I/D rows: 2 scope + 2 blocks + 2)
+    int kdepth2;               // impl 2: ring depth of the I / D rows (lazy I/D rows: scope + 2 blocks + 2, else kdepth)
     int kblock;                // impl 2: score levels per block (5: generic instance, 10: exact-penalty instance)
     void *bring;               // rows of brow offsets: M[(ring_scope+1)] | hot I1 I2 D1 D2 [ring_hot] each |
                                //   cold [(ring_scope+1)][4] | NULL row ; every aligner owns a sub-range of each row
     uint64_t bring_wg_stride;
     int brow;
     void *bhist;               // level-per-pass kernel: [hist_levels][5][bbase_jobs * hist_w] + NULL row; blocked kernel: hist_cap cells
-                               // that every batch of base cases lays out as [levels of the batch][5][sum of its widths], + a NULL row
+                               // in which every base case of a batch gets [its levels][5][its width], + a NULL row
     uint64_t bhist_wg_stride;
     uint64_t hist_cap;         // blocked kernel: cells of a workgroup's history (>= hist_levels * 5 * hist_w: one worst-case base case)
     uint32_t hist_stride;      // level-per-pass kernel: cells per history row (bbase_jobs * hist_w)
-    uint32_t hist_nul_w;       // blocked kernel: cells of the NULL row (widest batch: bbase_jobs * hist_w)
+    uint32_t hist_nul_w;       // blocked kernel: cells of the NULL row (a worst-case job's width + read slack)
     int bbase_jobs;
     int *bseg;                 // 2 segment lists of SR_BFS_MAXSEG records x SR_BFS_SEGREC ints
     uint32_t *bbt;             // [bbase_jobs][SR_BFS_BTCAP] reversed run-length ops of finished base cases
