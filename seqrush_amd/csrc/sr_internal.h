@@ -12,7 +12,7 @@
 #define SR_BFS_SEGREC 16             // ints per segment record
 #define SR_BFS_MAXACT 32             // segments searched concurrently (2 aligners each)
 #define SR_BFS_BTCAP 1024
-#define SR_BLK_MAK_SLOTS 112          // ring depth the blocked kernel supports (2 * scope + 2 * block + 2 = 74 for 0,5,8,2,24,1)
+#define SR_BLK_MAK_SLOTS 80          // ring depth the blocked kernel supports (2 * scope + 2 * block + 2 = 74 for 0,5,8,2,24,1)
 
 enum { SR_C_M = 0, SR_C_I1 = 1, SR_C_I2 = 2, SR_C_D1 = 3, SR_C_D2 = 4 };
 // raw WFA2 op codes used in device CIGAR ops: (len << 4) | op
