@@ -342,9 +342,9 @@ def main():
                 pmc = json.load(open(ppath))
             except Exception:
                 pmc = {}
-            if pmc.get("align_kernel") == ctx.align_kernel and pmc.get("align_hbm_bytes_per_launch"):
+            if ctx.align_kernel and ctx.align_kernel in str(pmc.get("align_kernel", "")) and pmc.get("align_hbm_bytes_per_launch"):
                 roof["traffic"] = pmc["align_hbm_bytes_per_launch"]
-                roof["traffic_source"] = {"file": "profiles/r03_counters.json", "recorded_kernel_ms": pmc.get("align_kernel_ms"),
+                roof["traffic_source"] = {"file": "profiles/r03_counters.json", "recorded_kernel": pmc.get("align_kernel"), "recorded_kernel_ms": pmc.get("align_kernel_ms"),
                                           "recorded_on": pmc.get("host"), "recorded_git": pmc.get("git"),
                                           "traffic_over_rows_counted": pmc["align_hbm_bytes_per_launch"] / rows_counted if rows_counted else None,
                                           "dram_bytes": pmc.get("align_dram_bytes_per_launch"),

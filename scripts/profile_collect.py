@@ -54,8 +54,11 @@ def main():
                     res[f"{k}_calls"] = int(row["Calls"])
     fetch = counters(os.path.join(d, "fetch")); write = counters(os.path.join(d, "write"))
     sq = counters(os.path.join(d, "sq1"))
-    for k, v in counters(os.path.join(d, "sq2")).items():
-        sq.setdefault(k, {}).update(v)
+    for sub in ("sq2", "tcc1", "tcc2"):
+        for k, v in counters(os.path.join(d, sub)).items():
+            sq.setdefault(k, {}).update(v)
+    res["host"] = os.environ.get("SR_PROFILE_HOST", "unknown")
+    res["git"] = os.environ.get("SR_PROFILE_GIT", "unknown")
     for k in ("align", "orient", "unite"):
         f = fetch.get(k, {}).get("FETCH_SIZE"); w = write.get(k, {}).get("WRITE_SIZE")
         if f is not None and w is not None:
@@ -66,6 +69,19 @@ def main():
                 res[f"{k}_hbm_GBps"] = res[f"{k}_hbm_bytes_per_launch"] / (res[f"{k}_kernel_ms"] * 1e-3) / 1e9
         for c, v in sq.get(k, {}).items():
             res[f"{k}:{c}"] = v
+        rd, wr = sq.get(k, {}).get("TCC_EA0_RDREQ_DRAM_32B_sum"), sq.get(k, {}).get("TCC_EA0_WRREQ_WRITE_DRAM_32B_sum")
+        if rd is not None and wr is not None:
+            # exact byte counts of the requests the L2 sent towards DRAM (Infinity-Cache hits included: no counter separates them)
+            res[f"{k}_dram_read_bytes_per_launch"] = rd * 32.0
+            res[f"{k}_dram_write_bytes_per_launch"] = wr * 32.0
+            res[f"{k}_dram_bytes_per_launch"] = (rd + wr) * 32.0
+            res[f"{k}_mall_hit_bytes_per_launch"] = None
+        hit, miss = sq.get(k, {}).get("TCC_HIT_sum"), sq.get(k, {}).get("TCC_MISS_sum")
+        if hit is not None and miss is not None and hit + miss > 0:
+            res[f"{k}_l2_hit_rate"] = hit / (hit + miss)
+        wa, wc = sq.get(k, {}).get("SQ_WAIT_ANY"), sq.get(k, {}).get("SQ_WAVE_CYCLES")
+        if wa and wc:
+            res[f"{k}_wait_any_frac"] = wa / wc
         insts, gui = sq.get(k, {}).get("SQ_INSTS_VALU"), sq.get(k, {}).get("GRBM_GUI_ACTIVE")
         if insts and gui:
             cycles = gui / 8.0                                   # GRBM_GUI_ACTIVE is summed over the 8 XCDs
