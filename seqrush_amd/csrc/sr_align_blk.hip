@@ -81,6 +81,9 @@ extern "C" int SRK_NAME(srk_align_blk)(const SrAlignArgs *a, int nwg, size_t lds
     if (a->kblock == 10) {
         if (off16) {
 #if SR_SYMBITS == 2
+#ifdef SR_PROF_WIDE   // (A/B builds only: tick counters for the 1024-thread shape)
+            if (nthreads == 1024 && two && a->profile_ticks) return launch_blk10<int16_t, 1024, true, true>(a, nwg, lds_bytes, st);
+#endif
             if (nthreads == 1024 && two) return launch_blk10<int16_t, 1024, true>(a, nwg, lds_bytes, st);    // fewer pairs than CUs
 #endif
             if (nthreads >= 512) return two ? launch_blk10<int16_t, 512, true>(a, nwg, lds_bytes, st) : launch_blk10<int16_t, 512, false>(a, nwg, lds_bytes, st);

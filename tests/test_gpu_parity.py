@@ -591,6 +591,17 @@ def test_deep_ring_penalties_run_on_the_wide_level_kernel(gpu, scores):
     check_parity(masked, scores=scores)
 
 
+@pytest.mark.parametrize("scores", ["0,6,58,2", "0,5,8,2,60,1", "0,9,20,2,70,1"])
+def test_deep_scope_on_the_generic_blocked_instance(gpu, scores):
+    """penalties the 5-level blocked instance serves with a scope of 61..72 levels: the breakpoint key's walk-order field
+    (level distance x 5 + component rank, up to 364) must not spill into the value (round 3: 8 -> 10 bits; the same slip
+    was fixed in the level-per-pass kernel).  Divergent sequences with long gaps so that overlaps are found deep in the
+    other aligner's scope window"""
+    recs = synth.indel_family(3, 1500, 0.06, 0.01, 3303, max_indel=90)
+    _, _, cnt = check_parity(recs, scores=scores)
+    assert cnt["align_kernel"] == "sr_align_blk_kernel", scores
+
+
 def test_penalties_without_blocked_instance_fall_back(gpu):
     """the blocked kernel is instantiated for gap-extend (2, 1) and blocks of 5 levels; other penalty sets
     run on the level-synchronous kernel and must match the oracle just the same"""
