@@ -5,7 +5,7 @@ set -e
 name=$1; flags=$2
 cd "$(dirname "$0")/../seqrush_amd/csrc"
 mkdir -p build_$name
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DSR_SYMBITS=2 $flags -c -o build_$name/sr_align_blk_s2.o sr_align_blk.hip
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DSR_SYMBITS=2 -DSR_BUILD_TAG="\"$name\"" $flags -c -o build_$name/sr_align_blk_s2.o sr_align_blk.hip
 objs=$(ls build/*.o | grep -v "build/sr_align_blk_s2.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../libseqrush_amd_$name.so $objs build_$name/sr_align_blk_s2.o
 echo built ../libseqrush_amd_$name.so

@@ -49,6 +49,10 @@ static int launch_blk10(const SrAlignArgs *a, int nwg, size_t lds_bytes, hipStre
 // penalty sets this build has a blocked instance for (host side asks before choosing impl 2): levels per block
 #if SR_SYMBITS == 2 && !defined(SR_BLK_WAVE)
 extern "C" int srk_align_blk_max_levels(void) { return KB_MAX; }
+#ifndef SR_BUILD_TAG
+#define SR_BUILD_TAG "default"
+#endif
+extern "C" const char *srk_align_blk_build_tag(void) { return SR_BUILD_TAG; }          // A/B builds name themselves (workspace report)
 extern "C" int srk_align_blk_supports(const SrPen *pen, const SrPen *ori) {
     if (ori->two || ori->e1 != 1 || ori->scope + 2 > BFS_MAK_SLOTS) return 0;
     if (pen->e1 != 2 || (pen->two && pen->e2 != 1)) return 0;

@@ -874,18 +874,18 @@ static int alloc_workspace(sr_ctx *c, const sr_params *p, const PackedSeqs &pk, 
 
 static void write_report(sr_ctx *c, const PackedSeqs &pk, const SrPen &pen, const Plan &pl) {
     const uint32_t np = (uint32_t)c->pair_q.size();
-    char buf[900];
+    char buf[1100];
     snprintf(buf, sizeof(buf),
              "{\"pairs\": %u, \"batches\": %u, \"symbol_bits\": %d, \"offset_bytes\": %zu, \"ring_cell_bytes\": %zu, \"kernel_impl\": %d, "
              "\"block_levels\": %d, \"two_piece\": %d, \"lazy_id_rows\": %d, \"workgroups\": %d, "
              "\"threads_per_workgroup\": %d, \"workgroups_per_cu\": %d, \"lds_dynamic_bytes\": %zu, \"ring_bytes_per_workgroup\": %llu, "
              "\"base_history_bytes_per_workgroup\": %llu, \"workspace_bytes\": %llu, \"cigar_arena_bytes\": %llu, "
-             "\"orientation_ring_bytes\": %llu, \"union_find_bytes\": %llu, \"device_free_bytes_at_load\": %zu}",
+             "\"orientation_ring_bytes\": %llu, \"union_find_bytes\": %llu, \"device_free_bytes_at_load\": %zu, \"kernel_build\": \"%s\"}",
              np, pl.nbatch, pk.sm.bits, pl.osz, pl.impl == 2 ? pl.rsz : pl.osz, pl.impl, pl.impl == 2 ? pl.kblock : 1, pen.two ? 1 : 0, pl.lazy_id,
              pl.nwg, c->nthreads, pl.wg_per_cu, c->lds_bytes,
              (unsigned long long)(pl.bring_wg * pl.rsz), (unsigned long long)(pl.bhist_wg * pl.osz),
              (unsigned long long)((uint64_t)pl.nwg * pl.per_wg_bytes), (unsigned long long)(pl.arena_ops * 4), (unsigned long long)pl.oring_bytes,
-             (unsigned long long)(3ULL * c->uf_size * 8), pl.free_b);
+             (unsigned long long)(3ULL * c->uf_size * 8), pl.free_b, srk_align_blk_build_tag());
     c->workspace_report = buf;
 }
 

@@ -144,6 +144,7 @@ int srk_graph_induce(const unsigned long long *labels, const uint8_t *bases, con
                      uint32_t *steps, uint8_t *node_base, unsigned long long *hkeys, uint32_t *hvals,
                      uint64_t hcap, uint32_t *eslot, unsigned long long *edges, uint32_t *tile_sum,
                      uint32_t *counts, int *error_flag, void *stream);
+const char *srk_align_blk_build_tag(void);                         // name of the blocked kernel's build (scripts/build_variant.sh)
 int srk_align_blk_max_levels(void);                                // deepest block of the build (static LDS tables)
 int srk_align_blk_supports(const SrPen *pen, const SrPen *ori);   // levels per block, 0 = no blocked instance
 int srk_labels32(unsigned long long *nodes, uint64_t uf_size, unsigned long long *minarr, uint32_t *labels, int *error_flag,
