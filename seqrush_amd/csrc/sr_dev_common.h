@@ -122,6 +122,65 @@ struct GroupIn {
     int mo1L, mo1R, i1L, d1R, mo2L, mo2R, i2L, d2R;
 };
 
+// ---- batched window reads of the blocked tiles (sr_align_blk.inc, sr_orient.hip) ----------------------------------
+#ifndef SR_LDS_WRAP
+#define SR_LDS_WRAP 0x1fffcu
+#endif
+#ifndef SR_NULL_NOEXT
+#define SR_NULL_NOEXT 0           // diagnostic builds (scripts/lds_oob): a cell below 0 gains nothing from its windows
+#endif
+// SR_WIN symbols starting at LDS-wide symbol index S (symbol 0 = the low bits of the word at LDS address 0)
+__device__ __forceinline__ uint32_t win_sym(int S) {
+    typedef uint32_t __attribute__((ext_vector_type(2), aligned(4))) W2;
+    // (the mask aligns the address to a word and wraps it into the first 128 KB: a cell that does not extend may point
+    // anywhere.  Reads beyond the workgroup's allocation return 0 and disturb nothing -- scripts/lds_oob)
+    const uint32_t addr = ((uint32_t)S >> (SR_WIN_LOG - 2)) & SR_LDS_WRAP;
+    const W2 w = *(const W2 __attribute__((address_space(3))) *)(uintptr_t)addr;
+    return __builtin_amdgcn_alignbit(w.y, w.x, (uint32_t)S << SR_SYM_LOG);
+}
+// the two words win_sym() takes its window from
+__device__ __forceinline__ void win_words(int S, uint32_t &lo, uint32_t &hi) {
+    typedef uint32_t __attribute__((ext_vector_type(2), aligned(4))) W2;
+    // (the mask aligns the address to a word and wraps it into the first 128 KB: a cell that does not extend may point
+    // anywhere.  Reads beyond the workgroup's allocation return 0 and disturb nothing -- scripts/lds_oob)
+    const uint32_t addr = ((uint32_t)S >> (SR_WIN_LOG - 2)) & SR_LDS_WRAP;
+    const W2 w = *(const W2 __attribute__((address_space(3))) *)(uintptr_t)addr;
+    lo = w.x; hi = w.y;
+}
+// the same for an LDS-wide BIT index (symbol index << SR_SYM_LOG): the index is also v_alignbit's shift amount
+__device__ __forceinline__ void win_words_bit(int Bx, uint32_t &lo, uint32_t &hi) {
+    typedef uint32_t __attribute__((ext_vector_type(2), aligned(4))) W2;
+    const uint32_t addr = ((uint32_t)Bx >> 3) & SR_LDS_WRAP;
+    const W2 w = *(const W2 __attribute__((address_space(3))) *)(uintptr_t)addr;
+    lo = w.x; hi = w.y;
+}
+// sext(16-bit half HI of w) * 2^SR_SYM_LOG + c in one instruction (v_mad_i32_i16): bit index of a packed cell's window
+template <int HI> __device__ __forceinline__ int bit_index(uint32_t w, int c) {
+    int r;
+    if (HI) asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(r) : "v"(w), "n"(1 << SR_SYM_LOG), "v"(c));
+    else asm("v_mad_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(w), "n"(1 << SR_SYM_LOG), "v"(c));
+    return r;
+}
+template <int HI> __device__ __forceinline__ int bit_index_u(uint32_t w, int c) {      // c wave-uniform (SGPR)
+    int r;
+    if (HI) asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(r) : "v"(w), "n"(1 << SR_SYM_LOG), "s"(c));
+    else asm("v_mad_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(w), "n"(1 << SR_SYM_LOG), "s"(c));
+    return r;
+}
+// equal leading symbols of an XOR-ed window: 2^31-1 >> .. (i.e. "all") when it is zero
+// (v_ffbl_b32 returns -1 for 0; __ffs() - 1 computes the same through a compare and a select the hardware does not need)
+__device__ __forceinline__ unsigned ffs_sym(uint32_t xw) {
+    unsigned r; asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(xw)); return r >> SR_SYM_LOG;
+}
+__device__ __forceinline__ unsigned min3u(unsigned a, unsigned b, unsigned c) {
+    unsigned r; asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
+}
+// v in the lanes of the mask, 0 elsewhere (the mask is a ballot: no per-lane flag register crosses the loop)
+__device__ __forceinline__ int lanes_or_zero(unsigned long long mask, int v) {
+    int r; asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(v), "s"(mask)); return r;
+}
+
+
 template <typename OT>
 __device__ __forceinline__ V4<OT> ld4(GP<OT> row, unsigned idx0) {
     return *(const V4<OT> __attribute__((address_space(1))) *)(row + idx0);

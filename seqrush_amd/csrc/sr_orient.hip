@@ -218,6 +218,9 @@ __global__ void __launch_bounds__(64, 4) sr_orient_blk_kernel(SrAlignArgs a) {
                         m1[qq] = (int)v1[qq]; m2[qq] = (int)v2[qq]; i1[qq] = (int)vi[qq]; d1[qq] = (int)vd[qq];
                         lim[qq] = (unsigned)max(min(tlen, plen + k0 + qq), -1);
                     }
+                    // LDS-wide symbol / bit index of P[-k0] and T[0]
+                    const int cp0 = -k0 + (int)(((uint32_t)(uintptr_t)P >> 2) << SR_WIN_LOG), ct0 = (int)(((uint32_t)(uintptr_t)T >> 2) << SR_WIN_LOG);
+                    const int cpb = cp0 << SR_SYM_LOG, ctb = ct0 << SR_SYM_LOG;
                     bool hit_now = false;
                     int hit_at = OB;
 #pragma unroll
@@ -244,53 +247,39 @@ __global__ void __launch_bounds__(64, 4) sr_orient_blk_kernel(SrAlignArgs a) {
                             mv[qq] = m; iv[qq] = in_; dv[qq] = dn_;
                         }
                         // extension of every cell of the wave (halo lanes feed owned cells of later levels).  The eight
-                        // window reads are in flight together; a NULL cell runs through the same code (its reads land
-                        // anywhere in or outside the LDS allocation, its value stays negative and is reset by bnd() at
-                        // the next level), only the "longer than a window" flag looks at validity.
-                        int more = 0;
+                        // window reads are in flight together, each addressed by its LDS-wide bit index (the read address
+                        // >> 3 and v_alignbit's shift at once); a NULL cell runs through the same code (its reads land
+                        // anywhere in or outside the LDS allocation and return what is there or 0, its value stays negative
+                        // and is reset by bnd() at the next level), only the "longer than a window" flag looks at validity.
+                        unsigned long long pend[4];
                         {
                             uint32_t pl[4], ph[4], tl[4], th[4];
+                            int bp[4], bt[4];
 #pragma unroll
                             for (int qq = 0; qq < 4; qq++) {
-                                // (byte addresses wrapped into the first 128 KB: a NULL cell points anywhere, and LDS reads far
-                                // outside the physical LDS are not harmless, see sr_align_blk.inc win_sym)
-                                const int h = mv[qq], v = mv[qq] - (k0 + qq);
-                                typedef uint32_t __attribute__((ext_vector_type(2), aligned(4))) W2;
-                                const uint32_t ap = ((uint32_t)(uintptr_t)P + (uint32_t)((v >> SR_WIN_LOG) << 2)) & 0x1fffcu;
-                                const uint32_t at = ((uint32_t)(uintptr_t)T + (uint32_t)((h >> SR_WIN_LOG) << 2)) & 0x1fffcu;
-                                const W2 wp = *(const W2 __attribute__((address_space(3))) *)(uintptr_t)ap;
-                                const W2 wt = *(const W2 __attribute__((address_space(3))) *)(uintptr_t)at;
-                                pl[qq] = wp.x; ph[qq] = wp.y; tl[qq] = wt.x; th[qq] = wt.y;
+                                bp[qq] = (mv[qq] << SR_SYM_LOG) + cpb - (qq << SR_SYM_LOG); bt[qq] = (mv[qq] << SR_SYM_LOG) + ctb;
+                                win_words_bit(bp[qq], pl[qq], ph[qq]); win_words_bit(bt[qq], tl[qq], th[qq]);
                             }
                             asm volatile("; 8 windows in flight" : "+v"(pl[0]), "+v"(ph[0]), "+v"(pl[1]), "+v"(ph[1]), "+v"(pl[2]), "+v"(ph[2]), "+v"(pl[3]), "+v"(ph[3]),
                                                                     "+v"(tl[0]), "+v"(th[0]), "+v"(tl[1]), "+v"(th[1]), "+v"(tl[2]), "+v"(th[2]), "+v"(tl[3]), "+v"(th[3]));
 #pragma unroll
                             for (int qq = 0; qq < 4; qq++) {
-                                const int h = mv[qq], v = mv[qq] - (k0 + qq);
-                                const int nn = (int)lim[qq] - h;
-                                const uint32_t xw = __builtin_amdgcn_alignbit(ph[qq], pl[qq], (uint32_t)v << SR_SYM_LOG) ^
-                                                    __builtin_amdgcn_alignbit(th[qq], tl[qq], (uint32_t)h << SR_SYM_LOG);
-                                const unsigned z = (unsigned)(__ffs((int)xw) - 1) >> SR_SYM_LOG;
-                                const bool valid = h >= 0;
-                                mv[qq] += (int)min(min(z, (unsigned)SR_WIN), (unsigned)nn);
-                                more |= (valid && xw == 0u && nn > SR_WIN) ? (1 << qq) : 0;
+                                const int nn = (int)lim[qq] - mv[qq];
+                                const uint32_t xw = __builtin_amdgcn_alignbit(ph[qq], pl[qq], (uint32_t)bp[qq]) ^
+                                                    __builtin_amdgcn_alignbit(th[qq], tl[qq], (uint32_t)bt[qq]);
+                                const int ext_ = (int)min3u(ffs_sym(xw), (unsigned)SR_WIN, (unsigned)nn);
+                                mv[qq] += ext_;
+                                pend[qq] = __builtin_amdgcn_ballot_w64(ext_ == SR_WIN) & __builtin_amdgcn_ballot_w64(mv[qq] >= 0);
                             }
                         }
-                        unsigned long long pend[4];
-#pragma unroll
-                        for (int qq = 0; qq < 4; qq++) pend[qq] = __ballot((more >> qq) & 1);
                         while ((pend[0] | pend[1] | pend[2] | pend[3]) != 0ull) {
 #pragma unroll
                             for (int qq = 0; qq < 4; qq++) {
                                 if (pend[qq] == 0ull) continue;
-                                const bool on = (more >> qq) & 1;
-                                const int h = on ? mv[qq] : 0, v = on ? mv[qq] - (k0 + qq) : 0;
-                                const int nn = on ? min(plen - v, tlen - h) : 0;
-                                const uint32_t xw = win_fwd(P, v) ^ win_fwd(T, h);
-                                const unsigned z = (unsigned)(__ffs((int)xw) - 1) >> SR_SYM_LOG;
-                                mv[qq] += (int)min(min(z, (unsigned)SR_WIN), (unsigned)nn);
-                                if (!(xw == 0u && nn > SR_WIN)) more &= ~(1 << qq);
-                                pend[qq] = __ballot((more >> qq) & 1);
+                                const int nn = lanes_or_zero(pend[qq], (int)lim[qq] - mv[qq]);      // 0 for the lanes that are done
+                                const uint32_t xw = win_sym(mv[qq] + cp0 - qq) ^ win_sym(mv[qq] + ct0);
+                                mv[qq] += (int)min3u(ffs_sym(xw), (unsigned)SR_WIN, (unsigned)nn);
+                                pend[qq] = __builtin_amdgcn_ballot_w64(xw == 0u && nn > SR_WIN);
                             }
                         }
                         if (!hit_now) {
