@@ -371,11 +371,11 @@ class Context:
                     breakpoint_searches=int(out[3]), united_bases=int(out[4]), match_runs=int(out[5]),
                     ticks_orientation=int(out[6]), ticks_breakpoint=int(out[7]), ticks_base=int(out[8]),
                     bp_passes=int(out[9]), ticks_pair=int(out[10]), tk_pass=int(out[11]),
-                    tk_barrier=int(out[12]), tk_control=int(out[13]), tk_phase2=int(out[14]),
+                    tk_barrier=int(out[12]), tk_setup_first=int(out[13]), tk_phase2=int(out[14]),
                     tk_tail=int(out[15]), bp_filter_units=int(out[19]), bp_candidates=int(out[20]),
                     bp_exact_units=int(out[21]), bp_rounds=int(out[22]), tk_backtrace=int(out[23]), tk_emit=int(out[24]),
                     st_wait_cycles=int(out[25]), st_body_cycles=int(out[26]), st_tiles=int(out[27]), st_ext_iters=int(out[28]),
-                    tk_p2_list=int(out[28]), tk_p2_filter=int(out[29]), tk_p2_exact=int(out[30]), tk_p2_replay=int(out[31]))
+                    tk_ctl_section=int(out[25]), tk_ctl_mak=int(out[26]), tk_ctl_segments=int(out[27]), tk_p2_list=int(out[28]), tk_p2_filter=int(out[29]), tk_p2_exact=int(out[30]), tk_p2_replay=int(out[31]))
 
     def close(self):
         if self._h:
