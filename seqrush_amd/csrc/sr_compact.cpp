@@ -289,6 +289,14 @@ void sr_graph_renumber(SrGraph &g) {                 // renumber_nodes_sequentia
 }
 
 // write_gfa, src/bidirected_ops.rs:880-925
+// decimal digits of v appended to out (the writer emits one number per node, two per edge and one per path step:
+// hundreds of thousands for C2, snprintf was most of the formatting time)
+static inline void put_u64(std::string &out, uint64_t v) {
+    char b[20];
+    int n = 0;
+    do { b[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) out += b[--n];
+}
 char *sr_graph_format_gfa(const SrGraph &g, const char *const *names, uint64_t *n_nodes, uint64_t *n_edges) {
     std::string out;
     size_t est = 64;
@@ -296,24 +304,21 @@ char *sr_graph_format_gfa(const SrGraph &g, const char *const *names, uint64_t *
     est += g.edges.size() * 32 + g.steps.size() * 9;
     out.reserve(est);
     out += "H\tVN:Z:1.0\n";
-    char tmp[96];
     uint64_t live = 0;
     for (size_t id = 0; id < g.node_seq.size(); id++) {
         if (!g.node_alive[id]) continue;
         live++;
-        snprintf(tmp, sizeof(tmp), "S\t%zu\t", id);
-        out += tmp; out += g.node_seq[id]; out += '\n';
+        out += "S\t"; put_u64(out, id); out += '\t'; out += g.node_seq[id]; out += '\n';
     }
     for (const auto &e : g.edges) {
-        snprintf(tmp, sizeof(tmp), "L\t%u\t%c\t%u\t%c\t0M\n", e.first >> 1, (e.first & 1) ? '-' : '+', e.second >> 1, (e.second & 1) ? '-' : '+');
-        out += tmp;
+        out += "L\t"; put_u64(out, e.first >> 1); out += (e.first & 1) ? "\t-\t" : "\t+\t";
+        put_u64(out, e.second >> 1); out += (e.second & 1) ? "\t-\t0M\n" : "\t+\t0M\n";
     }
     for (size_t p = 0; p + 1 < g.path_off.size(); p++) {
         out += "P\t"; out += names[p]; out += "\t";
         for (uint64_t i = g.path_off[p]; i < g.path_off[p + 1]; i++) {
             if (i != g.path_off[p]) out += ',';
-            snprintf(tmp, sizeof(tmp), "%u%c", g.steps[i] >> 1, (g.steps[i] & 1) ? '-' : '+');
-            out += tmp;
+            put_u64(out, g.steps[i] >> 1); out += (g.steps[i] & 1) ? '-' : '+';
         }
         out += "\t*\n";
     }
