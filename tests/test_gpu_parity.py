@@ -176,6 +176,8 @@ def test_50kb_pair_int32_offsets(gpu, monkeypatch, length, env):
     ss = SeqSet(recs); ctx = Context(0); ctx.load(ss, Params())
     rep = ctx.workspace_report(); ctx.close()
     assert rep["offset_bytes"] == 4 and rep["ring_cell_bytes"] == (2 if length <= 57000 and not env else 4)
+    # the report names the blocked kernel's build: "default" unless SEQRUSH_AMD_LIB points at an A/B library
+    assert rep["kernel_build"] == ("default" if not os.environ.get("SEQRUSH_AMD_LIB") else rep["kernel_build"])
     check_parity(recs)
 
 
