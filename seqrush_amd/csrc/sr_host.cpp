@@ -862,6 +862,17 @@ static int alloc_workspace(sr_ctx *c, const sr_params *p, const PackedSeqs &pk, 
     a.bring_wg_stride = pl.bring_wg; a.brow = pl.brow; a.bhist_wg_stride = pl.bhist_wg; a.bbase_jobs = pl.bbase_jobs;
     a.hist_cap = pl.hist_cap; a.hist_nul_w = (uint32_t)pl.hist_nul_w; a.hist_stride = (uint32_t)((uint64_t)pl.bbase_jobs * (uint64_t)pl.hist_w);
     a.cigar_base = c->d_cbase; a.counters = c->d_counters; a.error_flag = c->d_error;
+    // 8-mer sets of the sequences (8 KB each) for the orientation kernel's lower bound of the reverse orientation's score:
+    // plain ACGT buffers, default orientation penalties (the blocked orientation kernel), at most 256 MB and 5 % of what
+    // is left.  SR_NO_KBITS=1 switches the bound off (both orientations in lockstep from level 0, as before round 3).
+    if (a.pre_oriented && pk.sm.bits == 2 && !ori.two && ori.x == 1 && ori.o1 == 1 && ori.e1 == 1 && !getenv("SR_NO_KBITS") && !getenv("SR_ORIENT_LEVELS")) {
+        const uint64_t kb = (uint64_t)c->len.size() * 8192ull;
+        if (kb > 0 && kb <= (256ull << 20) && kb <= (uint64_t)(pl.left * 0.05)) {
+            if ((r = dev_alloc(c, &d, kb))) return r;
+            if ((r = srk_kmer_bits(&a, (uint32_t)c->len.size(), (uint32_t *)d, c->stream))) return fail(SR_ERR_DEVICE_FAULT, "k-mer set kernel failed to launch");
+            a.kbits = (const uint32_t *)d;
+        }
+    }
     SrUniteArgs &u = c->ua;
     memset(&u, 0, sizeof(u));
     u.pair_q = d_pq; u.pair_t = d_pt; u.npairs = np; u.seqlen = sd.len; u.seq_goff = sd.goff;

@@ -84,6 +84,8 @@ struct SrAlignArgs {
     uint64_t oring_wg_stride;
     int orow;
     uint32_t *oqueue;          // pair queue of the orientation kernel
+    const uint32_t *kbits;     // sr_orient_blk_kernel, 2-bit buffers: per sequence a 2^16-bit set of the 8-mers of its forward copy
+                               //   (q-gram bound of the reverse-complement orientation's score), NULL = none
     int pre_oriented;          // 1: is_reverse / ori_fwd / ori_rev are inputs of the alignment kernel
     int lazy_id;               // impl 2: searches in phase 1 do not store the I/D rows only breakpoint detection reads
                                //   (kdepth >= 2 * scope + 2 * block + 2 so that they can be recomputed)
@@ -135,6 +137,7 @@ int srk_merge(unsigned long long *nodes, uint64_t uf_size, const unsigned long l
               uint32_t count, int *error_flag, void *stream);
 int srk_align_max_lds(void);
 int srk_orient(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, void *stream);
+int srk_kmer_bits(const SrAlignArgs *a, uint32_t nseq, uint32_t *kbits, void *stream);      // build SrAlignArgs::kbits (2-bit buffers)
 // sr_order.hip: dequeue order of a batch by predicted cost (orientation score x length), sorted on the device
 size_t srk_order_temp_bytes(uint32_t n);
 int srk_order(const SrAlignArgs *a, uint64_t *keys_in, uint64_t *keys_out, uint32_t *vals_in, void *temp, size_t temp_bytes,

@@ -189,7 +189,33 @@ __global__ void __launch_bounds__(64, 4) sr_orient_blk_kernel(SrAlignArgs a) {
         const int shift = plen + 24, width = (plen + tlen + 64) & ~3, kend = tlen - plen;
         int fwd = -1, rev = INT_MAX, is_rev = 0;
         const long long smax = (long long)pen.o1 * 2 + (long long)pen.e1 * (plen + tlen) + 64;
-        for (int s0 = 0;; s0 += OB) {
+        // Lower bound of the reverse-complement orientation's score from the 8-mers its query shares with the target
+        // (a.kbits, see sr_kmer_bits_kernel): below that level the reverse aligner cannot reach the end, so only the forward
+        // one runs; if the forward aligner has not finished by then, the reverse one catches up block by block (its rows
+        // live in columns of their own) and the two go on in lockstep.  Outcome and scores are those of the lockstep.
+        int lb_rev = 0;
+#if SR_SYMBITS == 2
+        if (a.kbits && plen >= 8) {
+            const uint32_t *bm = a.kbits + (size_t)t * 2048;
+            const LP Prc = (LP)(lds_seq + a.max_words + 1);
+            const int npos = plen - 7;
+            int cnt = 0;
+            for (int i = lane; i < npos; i += 64) {
+                const uint32_t code = win_fwd(Prc, i) & 0xffffu;
+                cnt += (int)((bm[code >> 5] >> (code & 31u)) & 1u);
+            }
+            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+            lb_rev = (npos - cnt + 7) / 8;
+        }
+#endif
+        bool rev_on = lb_rev <= 0, catching = false;
+        int s0_main = 0, s0_catch = 0;
+        for (;;) {
+            if (!catching && !rev_on && s0_main + OB - 1 >= lb_rev) {
+                if (s0_main > 0) { catching = true; s0_catch = 0; } else rev_on = true;
+            }
+            const int s0 = catching ? s0_catch : s0_main;
+            const int jobmask = catching ? 2 : (rev_on ? 3 : 1);
             const int par = (s0 / OB) & 1;
             // rows of the previous block (NULL rows before the first one) and of this one
             GP<OT> pM1 = s0 ? ring + (size_t)((1 - par) * 4 + 0) * w : nul, pM2 = s0 ? ring + (size_t)((1 - par) * 4 + 1) * w : nul;
@@ -203,6 +229,7 @@ __global__ void __launch_bounds__(64, 4) sr_orient_blk_kernel(SrAlignArgs a) {
             int hitl[2] = {OB, OB};                              // first level of the block at which the aligner reached the end
 #pragma unroll
             for (int job = 0; job < 2; job++) {
+                if (!((jobmask >> job) & 1)) continue;
                 const LP P = (LP)(lds_seq + (job ? a.max_words : 0) + 1);
                 const int base = job * width;
                 for (int ti = 0; ti < nt; ti++) {
@@ -306,10 +333,18 @@ __global__ void __launch_bounds__(64, 4) sr_orient_blk_kernel(SrAlignArgs a) {
             // per level the reference checks the forward aligner first
             const int done = min(hitl[0], hitl[1]);
             const int lv = min(OB - 1, done);
+            const unsigned long long nal = (unsigned long long)__popc((unsigned)jobmask);       // aligners this block computed
             for (int j = 0; j <= lv; j++) {                      // level statistics as the level-by-level kernel counts them
                 const int R = reach(pen, s0 + j, SR_C_M);
-                cells += 2ull * (unsigned long long)(min(tlen, R) - max(-plen, -R) + 1);
-                steps += 2;
+                cells += nal * (unsigned long long)(min(tlen, R) - max(-plen, -R) + 1);
+                steps += nal;
+            }
+            if (catching) {
+                // (the forward aligner had not finished before s0_main: a reverse aligner that reaches the end here wins)
+                if (hitl[1] < OB) { rev = s0 + hitl[1]; is_rev = 1; break; }
+                s0_catch += OB;
+                if (s0_catch >= s0_main) { catching = false; rev_on = true; }
+                continue;
             }
             if (done < OB) {
                 if (hitl[0] <= hitl[1]) fwd = s0 + hitl[0];
@@ -317,6 +352,7 @@ __global__ void __launch_bounds__(64, 4) sr_orient_blk_kernel(SrAlignArgs a) {
                 break;
             }
             if (s0 + OB - 1 > smax) { err |= SR_DEV_ERR_SCORE_BOUND; break; }
+            s0_main += OB;
         }
         if (lane == 0) {
             a.is_reverse[pair] = is_rev ? 1 : 0;
@@ -333,6 +369,31 @@ __global__ void __launch_bounds__(64, 4) sr_orient_blk_kernel(SrAlignArgs a) {
 
 }  // namespace
 using namespace SR_NS;
+#if SR_SYMBITS == 2
+// One workgroup per sequence: the set of 8-mers (16 bits of the packed forward copy) that occur in it, as 2^16 bits.
+// sr_orient_blk_kernel counts how many 8-mer positions of the reverse-complemented query hit the target's set: by the
+// q-gram lemma an alignment with d edits leaves at least n - 7 - 8 d of them intact, so the reverse orientation's
+// score (>= its edit distance) is at least (positions - hits) / 8.
+__global__ void __launch_bounds__(256) sr_kmer_bits_kernel(SrAlignArgs a, uint32_t *kbits) {
+    const uint32_t sq = blockIdx.x;
+    uint32_t *bm = kbits + (size_t)sq * 2048;
+    for (int i = threadIdx.x; i < 2048; i += 256) bm[i] = 0u;
+    __syncthreads();
+    const int len = (int)a.seqlen[sq];
+    const uint32_t *w = a.seqwords + a.word_off_fwd[sq];
+    for (int i = threadIdx.x; i + 8 <= len; i += 256) {
+        const int wi = i >> 4, sh = (i & 15) << 1;
+        const uint64_t v = ((uint64_t)w[wi + 1] << 32) | (uint64_t)w[wi];
+        const uint32_t code = (uint32_t)(v >> sh) & 0xffffu;
+        atomicOr(&bm[code >> 5], 1u << (code & 31u));
+    }
+}
+extern "C" int srk_kmer_bits(const SrAlignArgs *a, uint32_t nseq, uint32_t *kbits, void *stream) {
+    if (nseq == 0) return 0;
+    hipLaunchKernelGGL(sr_kmer_bits_kernel, dim3(nseq), dim3(256), 0, (hipStream_t)stream, *a, kbits);
+    return (int)hipGetLastError();
+}
+#endif
 extern "C" int SRK_NAME(srk_orient)(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     const bool blocked = !a->ori.two && a->ori.x == 1 && a->ori.o1 == 1 && a->ori.e1 == 1 && !getenv("SR_ORIENT_LEVELS");

@@ -546,6 +546,34 @@ def test_orientation_kernel_and_in_kernel_orientation_agree(gpu, pre, monkeypatc
     ctx.close()
 
 
+@pytest.mark.parametrize("nokbits", ["", "1"])
+def test_orientation_bound_regimes(gpu, nokbits, monkeypatch):
+    """sr_orient_blk_kernel starts the reverse-complement aligner only at the level its 8-mer bound allows (round 3) and
+    lets it catch up when the forward one has not finished by then; SR_NO_KBITS=1 runs both from level 0.  Same strands,
+    orientation scores and alignments either way and as the oracle, in all three regimes: near-identical sequences (the
+    reverse aligner never runs), divergent ones (the bound is below the forward score: catch-up, then lockstep),
+    reverse-complemented members (the reverse aligner wins), plus sequences shorter than a k-mer"""
+    monkeypatch.setenv("SR_PREORIENT", "1")
+    if nokbits:
+        monkeypatch.setenv("SR_NO_KBITS", nokbits)
+    near = synth.snp_family(5, 2500, 0.01, 7711)
+    far = synth.snp_family(4, 1800, 0.16, 7712)
+    mixed = synth.snp_family(6, 1500, 0.05, 7713, rc_every=2) + [("tiny", b"ACGTA"), ("k", b"ACGTTGCAAC")]
+    outs = []
+    for recs in (near, far, mixed):
+        al, _, cnt = check_parity(recs)
+        outs.append((al.is_reverse.copy(), al.score.copy()))
+    assert not outs[0][0].any() and not outs[1][0].any() and outs[2][0].any()
+    ss = SeqSet(near); ctx = Context(0); ctx.load(ss, Params()); ctx.align(); ctx.sync()
+    cells = ctx.counters()["ticks_orientation"]               # (pre-oriented runs: the orientation kernel's cells)
+    ctx.close()
+    test_orientation_bound_regimes.cells = getattr(test_orientation_bound_regimes, "cells", {})
+    test_orientation_bound_regimes.cells[nokbits] = cells
+    if len(test_orientation_bound_regimes.cells) == 2:         # the bound halves the work on near-identical inputs
+        c = test_orientation_bound_regimes.cells
+        assert c[""] * 2 <= c["1"] + 64, c
+
+
 @pytest.mark.parametrize("seed", list(range(12)))
 def test_randomised_small_sets(gpu, seed):
     """seeded random sets: 2-6 sequences of length 1..400 derived from one base by substitutions, indels,
