@@ -79,8 +79,10 @@ typedef struct {
     uint64_t sparsify_seed;
     int32_t canonical_labels;   /* sr_align_and_unite: 1 = return min-Pos labels */
     int32_t device;             /* HIP device ordinal */
-    /* pair shard for multi-GPU: this call handles ordered pairs whose index
-     * in the (sparsified) row-major n*n list is == shard_rank mod shard_count */
+    /* pair shard for multi-GPU: this call handles shard `shard_rank` of `shard_count` of the (sparsified) row-major
+     * ordered pair list.  The shards are cost-balanced: pairs sorted by |q|*|t| (self pairs: |q|), longest first, each
+     * dealt to the rank with the least work so far (longest-processing-time-first; every rank computes the same
+     * assignment; equal lengths degenerate to index mod shard_count -- sr_host.cpp shard_pairs) */
     uint32_t shard_rank, shard_count;
     /* tree:neighbor[,stranger[,random[,k-mer]]] (seqrush.rs:378-418; extract_tree_pairs_separated call :941-947) */
     uint32_t tree_k_nearest, tree_k_farthest;
@@ -138,6 +140,20 @@ int sr_align_and_unite(const sr_seqset *seqs, const sr_params *p, uint64_t *pare
  * path compression): UFRush::find lib.rs:112-133, same :72-84 */
 uint64_t sr_uf_find(const uint64_t *nodes, uint64_t n, uint64_t x);
 int sr_uf_same(const uint64_t *nodes, uint64_t n, uint64_t x, uint64_t y);
+/* The same forest operations for hosts that build or merge node arrays WITHOUT a device (one thread, plain stores
+ * instead of CAS; identical packing, path halving, union by rank and tie rule -- larger index wins -- as
+ * uf_rush-0.2.1/src/lib.rs:112-208):
+ *   sr_uf_init_host             SeqRush::new state (src/seqrush.rs:308-336) for total_len bases, n >= 2*total_len+2
+ *   sr_uf_unite_host            UFRush::unite (lib.rs:159-208); returns 1 if two sets were joined, 0 if already one,
+ *                               negative on an index out of range (the reference panics, lib.rs:113)
+ *   sr_uf_merge_labels_host     SURVEY 8(e) merge: replay unite(i, labels_g[i]) for `count` gathered canonical label
+ *                               arrays (n entries each, back to back) into `nodes` -- the host twin of
+ *                               sr_ctx_merge_labels, for a Rust host that gathers per-GPU labels itself
+ *   sr_uf_canonical_labels_host minimum element of every set (== sr_ctx_download_labels of that forest) */
+int sr_uf_init_host(uint64_t *nodes, uint64_t n, uint64_t total_len);
+int sr_uf_unite_host(uint64_t *nodes, uint64_t n, uint64_t x, uint64_t y);
+int sr_uf_merge_labels_host(uint64_t *nodes, uint64_t n, const uint64_t *labels, uint32_t count);
+int sr_uf_canonical_labels_host(const uint64_t *nodes, uint64_t n, uint64_t *labels_out);
 
 /* -------- Seam 3: PAF interchange (seqrush.rs:510-609, 678-716) -------- */
 int sr_write_paf(const sr_alignments *a, const sr_seqset *seqs, const char *path);
@@ -243,6 +259,13 @@ int sr_build_gfa(const sr_seqset *seqs, const uint64_t *labels, char **gfa,
  * (src/bidirected_ops.rs:91-490), renumber_nodes_sequentially() (:75-89); compact == 0 is sr_build_gfa */
 int sr_build_gfa_opts(const sr_seqset *seqs, const uint64_t *labels, int compact, char **gfa,
                       uint64_t *n_nodes, uint64_t *n_edges);
+/* Induction from a RAW uf_rush node array with the reference's root rule (src/bidirected_builder.rs:46-48, 176-182: a
+ * node's base is the base at the offset of union_find.find(pos), i.e. of the component's ROOT): the entry point for a
+ * host that wants byte equality with a reference run -- node orientation on reverse-complement components included --
+ * by replaying the unites in a fixed order (its own uf_rush, or sr_uf_unite_host).  The canonical entry points above
+ * relabel every component to its minimum Pos first (schedule-independent). */
+int sr_build_gfa_from_nodes(const sr_seqset *seqs, const uint64_t *nodes, int compact, char **gfa,
+                            uint64_t *n_nodes, uint64_t *n_edges);
 int sr_ctx_build_gfa_opts(sr_ctx *c, const sr_seqset *seqs, int compact, char **gfa, uint64_t *n_nodes, uint64_t *n_edges);
 void sr_free(void *p);
 

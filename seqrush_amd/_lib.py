@@ -25,6 +25,8 @@ EXPORTS = [
     "sr_ctx_num_batches", "sr_ctx_workspace_report", "sr_ctx_run", "sr_ctx_align_all", "sr_ctx_pair_results",
     "sr_ctx_labels_device_u32", "sr_ctx_merge_labels_u32", "sr_ctx_counters_ext",
     "sr_build_gfa_opts", "sr_ctx_build_gfa_opts", "sr_ctx_merge_labels_host",
+    "sr_uf_init_host", "sr_uf_unite_host", "sr_uf_merge_labels_host", "sr_uf_canonical_labels_host",
+    "sr_build_gfa_from_nodes",
 ]
 
 
@@ -126,6 +128,11 @@ def load():
     L.sr_build_gfa.argtypes = [PS, C.POINTER(u64), C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
     L.sr_build_gfa_opts.argtypes = [PS, C.POINTER(u64), i32, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
     L.sr_ctx_build_gfa_opts.argtypes = [vp, PS, i32, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
+    L.sr_uf_init_host.argtypes = [C.POINTER(u64), u64, u64]
+    L.sr_uf_unite_host.argtypes = [C.POINTER(u64), u64, u64, u64]
+    L.sr_uf_merge_labels_host.argtypes = [C.POINTER(u64), u64, C.POINTER(u64), C.c_uint32]
+    L.sr_uf_canonical_labels_host.argtypes = [C.POINTER(u64), u64, C.POINTER(u64)]
+    L.sr_build_gfa_from_nodes.argtypes = [PS, C.POINTER(u64), i32, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
     L.sr_pair_list.argtypes = [C.c_uint32, PP, C.POINTER(C.POINTER(C.c_uint32)),
                                C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(u64)]
     L.sr_free.argtypes = [vp]; L.sr_free.restype = None

@@ -82,6 +82,11 @@ extern "C" int SRK_NAME(srk_align_blkw)(const SrAlignArgs *a, int nwg, size_t ld
 extern "C" int SRK_NAME(srk_align_blk)(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, int nthreads, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     const bool two = a->pen.two != 0;
+#ifdef SR_BLK_ONLY_PROD   // experiment builds (seconds instead of minutes, one kernel in the disassembly): the C2 / C4 production instance only
+    if (a->kblock == 10 && off16 && two && nthreads == 256 && !a->profile_ticks) return launch_blk10<int16_t, 256, true>(a, nwg, lds_bytes, st);
+    return -1;
+}
+#else
     if (a->kblock == 10) {
         if (off16) {
 #if SR_SYMBITS == 2
@@ -111,4 +116,5 @@ extern "C" int SRK_NAME(srk_align_blk)(const SrAlignArgs *a, int nwg, size_t lds
     }
     return two ? launch_blk3<int32_t, 256, true>(a, nwg, lds_bytes, st) : launch_blk3<int32_t, 256, false>(a, nwg, lds_bytes, st);
 }
+#endif   // SR_BLK_ONLY_PROD
 #endif

@@ -1565,6 +1565,65 @@ extern "C" int sr_uf_same(const uint64_t *nodes, uint64_t n, uint64_t x, uint64_
     return sr_uf_find(nodes, n, x) == sr_uf_find(nodes, n, y);
 }
 
+// Host-side uf_rush over a node array (same packing parent | rank << 58, path halving, union by rank, tie rule "larger
+// index wins" as uf_rush lib.rs:112-208; one thread, so the CAS loops collapse to plain stores).  For hosts that merge
+// per-GPU forests or replay unites themselves without a device: SURVEY 8(e)'s merge and 8(b)'s Seam 2 consumers.
+static const uint64_t UFH_MASK = 0x03FFFFFFFFFFFFFFULL;
+static inline uint64_t ufh_find(uint64_t *nodes, uint64_t x) {          // UFRush::find, lib.rs:112-133
+    uint64_t xn = nodes[x];
+    while (x != (xn & UFH_MASK)) {
+        const uint64_t par = xn & UFH_MASK, pp = nodes[par] & UFH_MASK;
+        nodes[x] = pp | (xn & ~UFH_MASK);                                // path halving: parent := grandparent, rank bits kept
+        x = pp; xn = nodes[x];
+    }
+    return x;
+}
+static inline bool ufh_unite(uint64_t *nodes, uint64_t x, uint64_t y) { // UFRush::unite, lib.rs:159-208
+    uint64_t xr = ufh_find(nodes, x), yr = ufh_find(nodes, y);
+    if (xr == yr) return false;
+    uint64_t xk = nodes[xr] >> 58, yk = nodes[yr] >> 58;
+    if (xk > yk || (xk == yk && xr > yr)) { std::swap(xr, yr); std::swap(xk, yk); }
+    nodes[xr] = yr | (xk << 58);
+    if (xk == yk) nodes[yr] = yr | ((yk + 1) << 58);
+    return true;
+}
+// SeqRush::new (src/seqrush.rs:308-336): 2N+2 nodes, unite(fwd(i), rev(i)) for every offset i, in order
+extern "C" int sr_uf_init_host(uint64_t *nodes, uint64_t n, uint64_t total_len) {
+    if (!nodes || n < 2 * total_len + 2) return fail(SR_ERR_INVALID, "node array shorter than 2 * total_len + 2");
+    for (uint64_t i = 0; i < n; i++) nodes[i] = i;
+    for (uint64_t i = 0; i < total_len; i++) ufh_unite(nodes, 2 * i, 2 * i + 1);
+    return SR_OK;
+}
+extern "C" int sr_uf_unite_host(uint64_t *nodes, uint64_t n, uint64_t x, uint64_t y) {
+    if (!nodes || x >= n || y >= n) return fail(SR_ERR_INVALID, "union-find index out of range");   // uf_rush panics (lib.rs:113)
+    return ufh_unite(nodes, x, y) ? 1 : 0;
+}
+// SURVEY 8(e) merge on the host: replay unite(i, labels_g[i]) for `count` label arrays of n entries laid out back to back
+extern "C" int sr_uf_merge_labels_host(uint64_t *nodes, uint64_t n, const uint64_t *labels, uint32_t count) {
+    if (!nodes || !labels) return fail(SR_ERR_INVALID, "null argument");
+    for (uint32_t g = 0; g < count; g++) {
+        const uint64_t *lab = labels + (uint64_t)g * n;
+        for (uint64_t i = 0; i < n; i++) {
+            if (lab[i] >= n) return fail(SR_ERR_INVALID, "label out of range");
+            if (lab[i] != i) ufh_unite(nodes, i, lab[i]);
+        }
+    }
+    return SR_OK;
+}
+// canonical labels of a node array: the minimum element of each set (what sr_ctx_download_labels returns)
+extern "C" int sr_uf_canonical_labels_host(const uint64_t *nodes, uint64_t n, uint64_t *labels_out) {
+    if (!nodes || !labels_out) return fail(SR_ERR_INVALID, "null argument");
+    std::vector<uint64_t> root(n), mn(n, UINT64_MAX);
+    for (uint64_t i = 0; i < n; i++) {
+        const uint64_t r = sr_uf_find(nodes, n, i);
+        if (r >= n) return fail(SR_ERR_INVALID, "node array is not a uf_rush forest");
+        root[i] = r;
+        if (mn[r] == UINT64_MAX) mn[r] = i;                              // ascending i: the first one seen is the minimum
+    }
+    for (uint64_t i = 0; i < n; i++) labels_out[i] = mn[root[i]];
+    return SR_OK;
+}
+
 // ------------------------------------------------------------------ PAF (seam 3)
 extern "C" int sr_write_paf(const sr_alignments *a, const sr_seqset *seqs, const char *path) {
     if (!a || !seqs || !path || !seqs->names) return fail(SR_ERR_INVALID, "null argument");
@@ -1660,6 +1719,23 @@ extern "C" int sr_build_gfa_opts(const sr_seqset *seqs, const uint64_t *labels, 
 }
 extern "C" int sr_build_gfa(const sr_seqset *seqs, const uint64_t *labels, char **gfa, uint64_t *n_nodes, uint64_t *n_edges) {
     return sr_build_gfa_opts(seqs, labels, 0, gfa, n_nodes, n_edges);
+}
+// The reference's own root rule (src/bidirected_builder.rs:46-48, 176-182): a node takes the base at the offset of its
+// component's union-find ROOT (union_find.find(pos)), whichever element the unite order made the root -- not the minimum
+// Pos the canonical entry points above use.  Given the raw uf_rush node array (sr_align_and_unite with canonical_labels
+// = 0, sr_ctx_download_uf, or an array a host built by replaying unites in its own fixed order through uf_rush /
+// sr_uf_unite_host), the representative of every element is its root and the induction is otherwise the same: GFA
+// byte equality with a reference run whose unites happened in that order, node orientation included.
+extern "C" int sr_build_gfa_from_nodes(const sr_seqset *seqs, const uint64_t *nodes, int compact, char **gfa,
+                                       uint64_t *n_nodes, uint64_t *n_edges) {
+    if (!seqs || !nodes || !gfa || !seqs->names) return fail(SR_ERR_INVALID, "null argument");
+    const uint64_t N = seqs->offsets[seqs->n], ufn = 2 * N + 2;
+    std::vector<uint64_t> root(ufn);
+    for (uint64_t i = 0; i < ufn; i++) {
+        root[i] = sr_uf_find(nodes, ufn, i);
+        if (root[i] >= ufn) return fail(SR_ERR_INVALID, "node array is not a uf_rush forest");
+    }
+    return sr_build_gfa_opts(seqs, root.data(), compact, gfa, n_nodes, n_edges);
 }
 
 // graph induction on the device from the context's union-find (sr_graph.hip); same

@@ -402,6 +402,49 @@ def build_gfa(seqset: SeqSet, labels: np.ndarray, compact: bool = False):
     return text, int(nn.value), int(ne.value)
 
 
+def build_gfa_from_nodes(seqset: SeqSet, nodes: np.ndarray, compact: bool = False):
+    """Graph induction from a RAW uf_rush node array with the reference's root rule (src/bidirected_builder.rs:46-48,
+    176-182: node base = base at the offset of the component's union-find root).  -> (gfa_text, n_nodes, n_edges)"""
+    L = _lib.load()
+    nodes = np.ascontiguousarray(nodes, dtype=np.uint64)
+    out = C.c_void_p(); nn = C.c_uint64(); ne = C.c_uint64()
+    check(L.sr_build_gfa_from_nodes(C.byref(seqset.c), nodes.ctypes.data_as(C.POINTER(C.c_uint64)), 1 if compact else 0,
+                                    C.byref(out), C.byref(nn), C.byref(ne)))
+    text = C.cast(out, C.c_char_p).value.decode()
+    L.sr_free(out)
+    return text, int(nn.value), int(ne.value)
+
+
+class HostUnionFind:
+    """uf_rush node array on the host (sr_uf_*_host: same packing / halving / rank / tie rule as uf_rush lib.rs:112-208,
+    one thread): SeqRush::new state, unite, merge of gathered canonical label arrays (SURVEY 8e), canonical labels."""
+
+    def __init__(self, total_len: int):
+        self.n = 2 * total_len + 2
+        self.nodes = np.zeros(self.n, dtype=np.uint64)
+        check(_lib.load().sr_uf_init_host(self._p(self.nodes), self.n, total_len))
+
+    @staticmethod
+    def _p(a):
+        return a.ctypes.data_as(C.POINTER(C.c_uint64))
+
+    def unite(self, x: int, y: int) -> bool:
+        r = _lib.load().sr_uf_unite_host(self._p(self.nodes), self.n, x, y)
+        if r < 0:
+            check(r)
+        return r == 1
+
+    def merge_labels(self, label_arrays):
+        lab = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.uint64) for a in label_arrays]))
+        assert len(lab) % self.n == 0
+        check(_lib.load().sr_uf_merge_labels_host(self._p(self.nodes), self.n, self._p(lab), len(lab) // self.n))
+
+    def canonical_labels(self) -> np.ndarray:
+        out = np.zeros(self.n, dtype=np.uint64)
+        check(_lib.load().sr_uf_canonical_labels_host(self._p(self.nodes), self.n, self._p(out)))
+        return out
+
+
 def uf_find(nodes: np.ndarray, x: int) -> int:
     nodes = np.ascontiguousarray(nodes, dtype=np.uint64)
     return int(_lib.load().sr_uf_find(nodes.ctypes.data_as(C.POINTER(C.c_uint64)), len(nodes), x))

@@ -1,8 +1,10 @@
 """CPU test of the multi-GPU scheme with world_size 2 over gloo: the product's
 pair sharding (sr_pair_list) + per-rank forests + ONE all-gather of canonical min-Pos labels +
 replay-unite must reproduce the single-process partition.  The per-rank alignment work is done
-by the oracle here (no GPU in this container); on the GPU box the same scheme runs through
-sr_ctx_labels_device / sr_ctx_merge_labels (tests/test_gpu_parity.py::test_label_merge_*)."""
+by the oracle here (no GPU in this container); the SHARD and the MERGE are the product's: sr_pair_list and
+sr_uf_init_host + sr_uf_merge_labels_host + sr_uf_canonical_labels_host (the host twins of the device merge;
+sr_ctx_merge_labels_host itself uploads into the context's device forest, so it needs a GPU and is covered by
+tests/test_gpu_parity.py::test_label_merge_* and the multi-rank bench / CLI tests there)."""
 import os
 import sys
 
@@ -33,12 +35,10 @@ def _worker(rank, world, port, q):
     lab = torch.from_numpy(o.canonical_labels().astype(np.int64))
     gathered = [torch.empty_like(lab) for _ in range(world)]
     dist.all_gather(gathered, lab)                 # the single exchange
-    L = ob.lib()
-    for g in gathered:                             # replay-unite
-        gl = g.numpy()
-        for i in np.nonzero(gl != np.arange(len(gl)))[0]:
-            L.sro_buf_unite(o.uf, int(i), int(gl[i]))
-    merged = o.canonical_labels()
+    from seqrush_amd.seqrush import HostUnionFind
+    h = HostUnionFind(sum(len(sq) for _, sq in recs))          # product: SeqRush::new forest on the host
+    h.merge_labels([g.numpy().astype(np.uint64) for g in gathered])   # product: replay-unite of the gathered label arrays
+    merged = h.canonical_labels()
     if rank == 0:
         ref = ob.OracleSeqRush(records=recs)
         ref.align_and_unite(op)

@@ -943,6 +943,35 @@ def test_full_size_c3_surrogate_parity(gpu):
             assert "".join(seg[s[:-1]] for s in f[2].split(",")) == dict(recs)[f[1]].decode()
 
 
+def _c3_fasta_path():
+    """Where a user who HAS the HLA-zoo DRB1 set points the C3 test / bench at it: SR_C3_FASTA, else the reference's own
+    path convention (HLA-zoo/seqs/DRB1-3123.fa relative to the working directory, /root/reference/src/bin/test_range_paf.rs:34)"""
+    p = os.environ.get("SR_C3_FASTA")
+    if p:
+        return p
+    for cand in ("HLA-zoo/seqs/DRB1-3123.fa", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "HLA-zoo", "seqs", "DRB1-3123.fa")):
+        if os.path.exists(cand):
+            return cand
+    return None
+
+
+def test_real_c3_hla_drb1_parity(gpu):
+    """BASELINE.json configs[2] on the REAL HLA-zoo DRB1 gene set when the file is there (SR_C3_FASTA=/path/DRB1-3123.fa):
+    every CIGAR, strand, score, the partition and the canonical GFA against the oracle, through the product's FASTA loader.
+    The set is an empty submodule of the reference checkout and is not obtainable in this pipeline (no network): skipped
+    with that message otherwise -- the surrogate test above stands in."""
+    path = _c3_fasta_path()
+    if not path or not os.path.exists(path):
+        pytest.skip("real C3 input absent: set SR_C3_FASTA=/path/to/HLA-zoo/seqs/DRB1-3123.fa (the HLA-zoo submodule of the "
+                    "reference checkout is empty and there is no network here); test_full_size_c3_surrogate_parity covers the surrogate")
+    from seqrush_amd.seqrush import load_sequences
+    seqs = load_sequences(path)
+    recs = [(s.id, bytes(s.data)) for s in seqs]
+    assert len(recs) >= 2
+    al, labels, cnt = check_parity(recs)
+    assert al.n == len(recs) ** 2
+
+
 def _component_bases_consistent(recs, labels):
     comp = np.zeros(256, dtype=np.uint8)
     for a, b in (b"AT", b"TA", b"CG", b"GC"):
@@ -1036,6 +1065,27 @@ def test_full_size_c5_properties(gpu):
         assert int(al.score[i]) == int(S[q, t]) and bool(al.is_reverse[i]) == bool(R[q, t])
         qs = synth.reverse_complement(recs[q][1]) if al.is_reverse[i] else recs[q][1]
         assert ob.cigar_score(al.raw_cigar_bytes(i), qs, recs[t][1], pen) == int(S[q, t])
+    # Round 4: a CIGAR that costs its score is not yet the oracle's CIGAR, nor the score the optimum.
+    # Twelve pairs of the full run -- the 3 highest scores, 3 reversed pairs, 6 drawn at random (seeded) -- against the
+    # oracle's biWFA (o.align_pair: orientation, score and the raw CIGAR byte for byte), on as many host threads as there
+    # are CPUs (ctypes releases the GIL, the oracle's arenas are per thread).
+    import concurrent.futures as cf
+    rng = np.random.default_rng(5004)
+    off = [(q, t) for q in range(n) for t in range(n) if q != t]
+    revp = [(q, t) for (q, t) in off if R[q, t]]
+    pick = [(int(i) // n, int(i) % n) for i in order[-3:]]
+    pick += [revp[int(i)] for i in rng.choice(len(revp), 3, replace=False)]
+    pick += [off[int(i)] for i in rng.choice(len(off), 6, replace=False)]
+    c3 = Context(0); c3.load_pairs(ss, Params(), pick); c3.run(); c3.sync(); al2 = c3.alignments(); c3.close()
+    o = ob.OracleSeqRush(records=recs)
+    op = ob.default_params(); op.threads = 1
+    with cf.ThreadPoolExecutor(max_workers=min(len(pick), usable_cpus())) as ex:
+        want = list(ex.map(lambda qt: o.align_pair(op, qt[0], qt[1]), pick))
+    for i, (q, t) in enumerate(pick):
+        assert int(al2.score[i]) == want[i]["score"] == int(S[q, t]), f"score differs from the oracle on pair ({q},{t})"
+        assert bool(al2.is_reverse[i]) == want[i]["is_reverse"]
+        assert al2.raw_cigar_bytes(i) == want[i]["cigar"], f"CIGAR differs from the oracle on pair ({q},{t})"
+    o.close()
 
 
 def test_compaction_after_device_induction(gpu):

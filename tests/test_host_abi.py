@@ -248,6 +248,80 @@ def test_uf_find_helper():
         assert uf_find(nodes, x) == o.find(x)
 
 
+def test_host_union_find_is_uf_rush_bit_for_bit():
+    """sr_uf_init_host / sr_uf_unite_host against the oracle's uf_rush restatement (uf_rush-0.2.1/src/lib.rs:112-208): after
+    SeqRush::new and the same sequence of unites the NODE ARRAYS are equal word for word (parent, rank bits, halving)"""
+    from seqrush_amd.seqrush import HostUnionFind
+    total = 300
+    h = HostUnionFind(total)
+    L = ob.lib()
+    u = L.sro_buf_new(total)
+    for i in range(total):                                   # SeqRush::new (src/seqrush.rs:324-328)
+        L.sro_buf_unite(u, 2 * i, 2 * i + 1)
+    n = L.sro_uf_size(u)
+    assert n == h.n
+    grab = lambda: np.ctypeslib.as_array(L.sro_uf_nodes(u), shape=(n,)).copy()
+    assert np.array_equal(grab(), h.nodes)
+    rng = np.random.default_rng(77)
+    for _ in range(2000):
+        x, y = (int(v) for v in rng.integers(0, 2 * total, 2))
+        before = bool(L.sro_buf_same(u, x, y))
+        L.sro_buf_unite(u, x, y)
+        assert h.unite(x, y) == (not before)
+    assert np.array_equal(grab(), h.nodes)
+    with pytest.raises(sa.SeqRushError):
+        h.unite(0, h.n)                                      # the reference panics on an index out of range (lib.rs:113)
+    lab = h.canonical_labels()
+    for x in range(0, h.n, 7):
+        assert lab[x] == min(y for y in range(h.n) if L.sro_buf_same(u, x, y)) if x < 40 else lab[lab[x]] == lab[x]
+
+
+def test_host_label_merge_reproduces_the_single_forest():
+    """sr_uf_merge_labels_host (SURVEY 8e on the host): forests of the product's pair shards, exchanged as canonical label
+    arrays and replayed into a fresh SeqRush::new forest, give the partition of the unsharded run -- for 2, 3 and 5 shards"""
+    from seqrush_amd.seqrush import HostUnionFind
+    recs = synth.snp_family(6, 160, 0.05, 31, rc_every=3)
+    ref = _oracle_labels(recs).canonical_labels()
+    total = sum(len(s) for _, s in recs)
+    for world in (2, 3, 5):
+        gathered = []
+        for rank in range(world):
+            prm = Params(); prm.c.shard_rank, prm.c.shard_count = rank, world
+            o = ob.OracleSeqRush(records=recs)
+            op = ob.default_params()
+            for (qi, ti) in pair_list(len(recs), prm):
+                a = o.align_pair(op, qi, ti)
+                assert o.process_alignment(ob.cigar_bytes_to_string(a["cigar"]), qi, ti, 0, a["is_reverse"]) >= 0
+            gathered.append(o.canonical_labels())
+            o.close()
+        h = HostUnionFind(total)
+        h.merge_labels(gathered)
+        assert np.array_equal(h.canonical_labels(), ref)
+
+
+@pytest.mark.parametrize("name,recs", [
+    ("rc", synth.snp_family(6, 200, 0.04, 5, rc_every=2)),
+    ("rc-indel", [(n, s if i % 2 else synth.reverse_complement(s)) for i, (n, s) in enumerate(synth.indel_family(4, 300, 0.03, 0.03, 16))]),
+    ("snp", synth.snp_family(4, 250, 0.05, 3)),
+])
+def test_gfa_from_raw_nodes_uses_the_root_rule(name, recs):
+    """sr_build_gfa_from_nodes: node base = base at the offset of the component's uf_rush ROOT, the reference's own rule
+    (src/bidirected_builder.rs:46-48, 176-182), so that a host which replays the unites in a fixed order gets the
+    reference's node orientation too.  Against the oracle's non-canonical induction on its own (sequentially built)
+    forest: byte-identical GFA, also after compaction; and with canonical labels as "nodes" it degenerates to sr_build_gfa."""
+    from seqrush_amd.seqrush import build_gfa_from_nodes
+    o = _oracle_labels(recs)
+    ss = SeqSet(recs)
+    g_prod, nn, ne = build_gfa_from_nodes(ss, o.nodes())
+    g_orc, on, oe = o.gfa(canonical=False)
+    assert (nn, ne) == (on, oe) and g_prod == g_orc
+    gc_prod, cn, ce = build_gfa_from_nodes(ss, o.nodes(), compact=True)
+    gc_orc, con, coe = ob.compact_gfa(g_orc)
+    assert (cn, ce) == (con, coe) and canon_gfa(gc_prod) == canon_gfa(gc_orc)
+    lab = o.canonical_labels()
+    assert build_gfa_from_nodes(ss, lab) == build_gfa(ss, lab)       # a label array is a (flat) forest
+
+
 def test_aligner_backend_names():
     """src/aligner.rs:42-52, 64-96"""
     assert sa.AlignerBackend.from_str("AllWave") == sa.AlignerBackend.AllWave
