@@ -247,6 +247,15 @@ int sr_ctx_counters(sr_ctx *c, uint64_t out[16]);
  * every tile counted on the device: the kernel's algorithmic HBM bytes, bench.py roofline); [18..31] reserved.
  * The tick counters [6..15] are filled only by the instrumented kernel instance (environment SR_PROFILE_TICKS=1). */
 int sr_ctx_counters_ext(sr_ctx *c, uint64_t out[32]);
+/* every slot (48 since ABI 2 / round 4): [32..35] tile stamps of the diagnostic build (cycles waiting for a tile's first
+ * rows, cycles in its levels, tiles, extension-loop iterations), [36] bytes of wavefront rows that stayed in LDS
+ * (LDS-resident histories of small base cases), [37] base cases searched again with the worst-case history region,
+ * [40..43] first offending access of the bounds-checked build (pair, level, row offset, extent), rest reserved.
+ * Returns the number of slots written (<= cap) or a negative sr_status. */
+int sr_ctx_counters_all(sr_ctx *c, uint64_t *out, uint32_t cap);
+/* "NAME<TAB>meaning when unset<TAB>what it does" lines of every environment variable the load path reads; the ones that
+ * are set are listed under "knobs" in sr_ctx_workspace_report() */
+const char *sr_knobs_doc(void);
 
 /* -------- consumer (A9): graph induction + GFA, host C++ -----------------
  * build_bidirected_graph_with_options (bidirected_builder.rs:17-289) +

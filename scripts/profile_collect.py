@@ -54,7 +54,7 @@ def main():
                     res[f"{k}_calls"] = int(row["Calls"])
     fetch = counters(os.path.join(d, "fetch")); write = counters(os.path.join(d, "write"))
     sq = counters(os.path.join(d, "sq1"))
-    for sub in ("sq2", "tcc1", "tcc2"):
+    for sub in ("sq2", "tcc1", "tcc2", "sq3", "sq4"):
         for k, v in counters(os.path.join(d, sub)).items():
             sq.setdefault(k, {}).update(v)
     res["host"] = os.environ.get("SR_PROFILE_HOST", "unknown")
@@ -83,6 +83,12 @@ def main():
         if wa and wc:
             res[f"{k}_wait_any_frac"] = wa / wc
         insts, gui = sq.get(k, {}).get("SQ_INSTS_VALU"), sq.get(k, {}).get("GRBM_GUI_ACTIVE")
+        if insts:
+            res[f"{k}_valu_insts"] = insts
+            res[f"{k}_salu_insts"] = sq.get(k, {}).get("SQ_INSTS_SALU")
+        ireq, imiss = sq.get(k, {}).get("SQC_ICACHE_REQ"), sq.get(k, {}).get("SQC_ICACHE_MISSES")
+        if ireq and imiss is not None:
+            res[f"{k}_icache_miss_rate"] = imiss / ireq
         if insts and gui:
             cycles = gui / 8.0                                   # GRBM_GUI_ACTIVE is summed over the 8 XCDs
             res[f"{k}_busy_cycles"] = cycles

@@ -26,7 +26,7 @@ EXPORTS = [
     "sr_ctx_labels_device_u32", "sr_ctx_merge_labels_u32", "sr_ctx_counters_ext",
     "sr_build_gfa_opts", "sr_ctx_build_gfa_opts", "sr_ctx_merge_labels_host",
     "sr_uf_init_host", "sr_uf_unite_host", "sr_uf_merge_labels_host", "sr_uf_canonical_labels_host",
-    "sr_build_gfa_from_nodes",
+    "sr_build_gfa_from_nodes", "sr_ctx_counters_all", "sr_knobs_doc",
 ]
 
 
@@ -116,6 +116,8 @@ def load():
     L.sr_ctx_build_gfa.argtypes = [vp, PS, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
     L.sr_ctx_counters.argtypes = [vp, C.POINTER(u64)]
     L.sr_ctx_counters_ext.argtypes = [vp, C.POINTER(u64)]
+    L.sr_ctx_counters_all.argtypes = [vp, C.POINTER(u64), C.c_uint32]
+    L.sr_knobs_doc.restype = C.c_char_p
     L.sr_ctx_load_pairs.argtypes = [vp, PS, PP, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), u64]
     L.sr_ctx_pairs.argtypes = [vp, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(u64)]
     L.sr_ctx_num_batches.argtypes = [vp]; L.sr_ctx_num_batches.restype = C.c_uint32

@@ -15,6 +15,17 @@
 #define SR_BLK_SUB wg4
 #endif
 #define BFS_MAK_SLOTS SR_BLK_MAK_SLOTS
+// The backtrace of a base case is inlined into the blocked kernel (round 4).  As a real call (it was the kernel's only one) it
+// handed its op count back through `int *n_out`, a stack slot the callee writes with a flat store and the caller reads
+// back with scratch_load, from a kernel that lives on ~100 spilled VGPRs and ~450 SGPRs spilled into VGPR lanes.  In
+// some instances of the kernel -- which ones changes with register allocation, i.e. with unrelated edits and with debug
+// prints -- the caller then continued with a stale count (a CIGAR short of its first run) and wrong uniform values (a
+// mismatch penalty of 0 in the score of the CIGAR), or left the private aperture ("Memory access fault", round 3's
+// "unexplained" faults and this round's first runs of the 512-thread 32-bit instance).  Same source, SR_BT_ATTR =
+// __noinline__: wrong / faulting; __forceinline__: right (profiles/r04_backtrace_call.log).  DESIGN.md section 4.1.
+#ifndef SR_BT_ATTR
+#define SR_BT_ATTR __forceinline__
+#endif
 namespace SR_NS { namespace SR_BLK_SUB {
 #include "sr_align_bfs.inc"
 #ifndef SR_BLK_MIN_WAVES
@@ -56,8 +67,9 @@ extern "C" const char *srk_align_blk_build_tag(void) { return SR_BUILD_TAG; }   
 extern "C" int srk_align_blk_supports(const SrPen *pen, const SrPen *ori) {
     if (ori->two || ori->e1 != 1 || ori->scope + 2 > BFS_MAK_SLOTS) return 0;
     if (pen->e1 != 2 || (pen->two && pen->e2 != 1)) return 0;
-    if (pen->x == 5 && pen->o1 + pen->e1 == 10 && (!pen->two || pen->o2 + pen->e2 >= 10) &&
-        2 * pen->scope + 2 * 10 + 2 <= BFS_MAK_SLOTS) return 10;
+    // (second gap piece a multiple of five levels back: the tile reads M[s - o2 - e2] as two runs of five adjacent rows)
+    if (pen->x == 5 && pen->o1 + pen->e1 == 10 && (!pen->two || (pen->o2 + pen->e2 >= 10 && (pen->o2 + pen->e2) % 5 == 0)) &&
+        (2 * pen->scope + 2 * 10 + 2 + 9) / 10 * 10 <= BFS_MAK_SLOTS) return 10;
     const int B = 5;
     if (pen->x < B || pen->o1 + pen->e1 < B) return 0;
     if (pen->two && pen->o2 + pen->e2 < B) return 0;
@@ -82,7 +94,11 @@ extern "C" int SRK_NAME(srk_align_blkw)(const SrAlignArgs *a, int nwg, size_t ld
 extern "C" int SRK_NAME(srk_align_blk)(const SrAlignArgs *a, int nwg, size_t lds_bytes, int off16, int nthreads, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     const bool two = a->pen.two != 0;
-#ifdef SR_BLK_ONLY_PROD   // experiment builds (seconds instead of minutes, one kernel in the disassembly): the C2 / C4 production instance only
+#ifdef SR_BLK_ONLY_C5     // experiment builds: the C5 instance only (32-bit search, 16-bit ring, 512 threads)
+    if (a->kblock == 10 && !off16 && two && a->ring_u16 && nthreads == 512) return launch_blk10<int32_t, 512, true, false, uint16_t>(a, nwg, lds_bytes, st);
+    return -1;
+}
+#elif defined(SR_BLK_ONLY_PROD)   // experiment builds (seconds instead of minutes, one kernel in the disassembly): the C2 / C4 production instance only
     if (a->kblock == 10 && off16 && two && nthreads == 256 && !a->profile_ticks) return launch_blk10<int16_t, 256, true>(a, nwg, lds_bytes, st);
     return -1;
 }

@@ -23,6 +23,58 @@
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 extern "C" const char *sr_last_error(void) { return g_err.c_str(); }
+
+// ------------------------------------------------------------------ environment knobs
+// Every environment variable the load path reads, in ONE table: name, what unset means, what it does.  knob() is the only
+// place that calls getenv for them and refuses a name that is not listed; sr_ctx_workspace_report() dumps every knob that is
+// set ("knobs": {...}), so a measurement carries every non-default setting it ran with.
+struct SrKnob { const char *name, *unset, *doc; };
+static const SrKnob SR_KNOBS[] = {
+    {"SR_ALIGN_IMPL", "2 when the penalties have a blocked instance", "1 = level-per-pass kernel (sr_align_bfs_kernel), 2 = score-blocked kernel"},
+    {"SR_BLK_LEVELS", "10 for x=5, o1+e1=10", "5 = generic 5-level blocked instance instead of the exact 10-level one"},
+    {"SR_ALIGN_THREADS", "by pairs per CU", "threads per workgroup: 64 | 128 | 256 | 512 | 1024"},
+    {"SR_WG_PER_CU", "4", "workgroups per CU the launch is sized for"},
+    {"SR_NWG", "CUs x workgroups per CU", "cap on workgroups (several pairs per workgroup on small inputs)"},
+    {"SR_STATIC_LDS_KB", "22 / 28 / 6", "static LDS of the kernel assumed when sizing workgroups per CU (A/B builds with other tables)"},
+    {"SR_RING_U16", "1 below 57 k", "0 = 32-bit searches keep 32-bit ring rows"},
+    {"SR_LAZY_ID", "1", "0 = searches store their I/D rows from the first level (no recompute pass)"},
+    {"SR_HIST_JOBS", "4", "worst-case base cases the per-workgroup history holds (1..16)"},
+    {"SR_BFS_BASE_JOBS", "16 (lean builds 4 / 8)", "base cases per batch"},
+    {"SR_CIGAR_ARENA_OPS", "25 % of free memory", "CIGAR arena in ops (tests: force batches)"},
+    {"SR_POISON_ROWS", "off", "fill the row workspaces with this offset before the run (stale-row tests)"},
+    {"SR_PREORIENT", "by pairs per CU and LDS", "1 / 0 = orientation as its own kernel / inside the alignment kernel"},
+    {"SR_NO_REORDER", "off", "keep list order instead of the cost-sorted dequeue order"},
+    {"SR_ORIENT_LEVELS", "off", "orientation level by level even for the default penalties"},
+    {"SR_NO_KBITS", "off", "no q-gram bound in the orientation kernel"},
+    {"SR_PROFILE_TICKS", "0", "1 = launch the instrumented instance (100 MHz tick counters)"},
+    {"SR_FORCE_INT32", "off", "tests: 32-bit offsets (and the 16-bit ring of 32-bit searches) whatever the sequence length"},
+    {"SR_TEST_BASE_LEVELS", "off", "tests: cap on the levels a base case is given at first (forces the re-queue path)"},
+    {"SR_BOUNDS_DETAIL", "off", "1 = (bounds-checked build) keep the first offending access in counters[40..43]"},
+};
+static const char *knob(const char *name) {
+    for (const SrKnob &k : SR_KNOBS)
+        if (!strcmp(k.name, name)) return getenv(name);
+    fprintf(stderr, "seqrush_amd: internal error: environment knob %s is not in SR_KNOBS\n", name);
+    abort();
+}
+static std::string knobs_json() {
+    std::string out = "{";
+    for (const SrKnob &k : SR_KNOBS)
+        if (const char *v = getenv(k.name)) {
+            if (out.size() > 1) out += ", ";
+            out += std::string("\"") + k.name + "\": \"";
+            for (const char *q = v; *q; q++) if (*q != '"' && *q != '\\' && (unsigned char)*q >= 32) out += *q;
+            out += "\"";
+        }
+    return out + "}";
+}
+// (name, unset, doc) lines of the table: `seqrush_mi355x --knobs`, scripts
+extern "C" const char *sr_knobs_doc(void) {
+    static std::string doc;
+    if (doc.empty())
+        for (const SrKnob &k : SR_KNOBS) doc += std::string(k.name) + "\t" + k.unset + "\t" + k.doc + "\n";
+    return doc.c_str();
+}
 extern "C" int sr_abi_version(void) { return SR_ABI_VERSION; }
 extern "C" void sr_free(void *p) { free(p); }
 extern "C" int sr_device_count(void) {
@@ -621,6 +673,7 @@ static int plan_kernel(sr_ctx *c, const PackedSeqs &pk, const SrPen &pen, const 
     pl.cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const int cus = pl.cus, bits = pk.sm.bits;
     c->off16 = maxlen <= 32000 ? 1 : 0;
+    if (knob("SR_FORCE_INT32")) c->off16 = 0;             // (tests: the 32-bit searches and their 16-bit ring on short sequences)
     pl.osz = c->off16 ? 2 : 4;
     pl.max_words = (uint32_t)((maxlen + pk.per_word - 1) / pk.per_word + 2);
     c->lds_bytes = (size_t)pl.max_words * 3 * 4;          // query fwd / rc + target fwd
@@ -629,22 +682,22 @@ static int plan_kernel(sr_ctx *c, const PackedSeqs &pk, const SrPen &pen, const 
     pl.impl = 1;
     pl.kblock = srk_align_blk_supports(&pen, &ori);
     // SR_BLK_LEVELS=5: the generic 5-level instance instead of the exact-penalty 10-level one (A/B runs, tests)
-    if (const char *e = getenv("SR_BLK_LEVELS")) { if (atoi(e) == 5 && pl.kblock == 10) pl.kblock = 5; }
+    if (const char *e = knob("SR_BLK_LEVELS")) { if (atoi(e) == 5 && pl.kblock == 10) pl.kblock = 5; }
     // (the blocked kernel stages four sequence copies, has ~20 KB of static LDS and keeps its LDS window addresses within
     // 128 KB: static tables + copies must fit below; it has its own ring depth limit, srk_align_blk_supports)
     if (pl.kblock > 0 && (long long)pl.max_words * 16 + 28 * 1024 <= 128 * 1024) pl.impl = 2;
-    if (const char *e = getenv("SR_ALIGN_IMPL")) { if (atoi(e) <= 1) pl.impl = 1; }      // (tests: the level-per-pass kernel)
+    if (const char *e = knob("SR_ALIGN_IMPL")) { if (atoi(e) <= 1) pl.impl = 1; }      // (tests: the level-per-pass kernel)
     int &impl = pl.impl, &kblock = pl.kblock;
     if (impl == 2) c->lds_bytes = (size_t)pl.max_words * 4 * 4 + 16;      // (+ read slack of a two-window extension step)
     pl.wg_per_cu = 4;
-    if (const char *e = getenv("SR_WG_PER_CU")) pl.wg_per_cu = std::max(1, atoi(e));
+    if (const char *e = knob("SR_WG_PER_CU")) pl.wg_per_cu = std::max(1, atoi(e));
     c->nthreads = 256;
     // few pairs (e.g. the 1/8 shard of C2): one pair per workgroup leaves CUs short of waves, so give every
     // pair 8 waves instead of 4 (measured 31 -> 23 ms for 529 pairs of 5 kb)
     if (impl == 2 && (uint64_t)np <= 2ULL * (uint64_t)cus + (uint64_t)cus / 2) c->nthreads = 512;
     // fewer pairs than CUs (C3: 144): a pair has a CU to itself -- 16 waves (C3 90.1 -> 69.2 ms)
     if (impl == 2 && (uint64_t)np <= (uint64_t)cus) c->nthreads = 1024;
-    if (const char *e = getenv("SR_ALIGN_THREADS")) {
+    if (const char *e = knob("SR_ALIGN_THREADS")) {
         const int v = atoi(e);
         if (v == 128 || v == 256 || v == 512 || (v == 1024 && impl == 2) || (v == 64 && impl == 2 && bits == 2)) c->nthreads = v;
     }
@@ -653,21 +706,21 @@ static int plan_kernel(sr_ctx *c, const PackedSeqs &pk, const SrPen &pen, const 
     pl.wave_wg = impl == 2 && (c->nthreads == 64 || (c->nthreads == 128 && kblock == 10));   // lean builds: 16 / 8 pairs per CU
     if (pl.wave_wg) pl.wg_per_cu = c->nthreads == 64 ? 16 : 8;
     size_t lds_static = (size_t)(pl.wave_wg ? 6 : impl == 2 ? 22 : 28) * 1024;      // static tables of the kernel (upper estimate)
-    if (const char *e = getenv("SR_STATIC_LDS_KB")) lds_static = (size_t)std::max(1, atoi(e)) * 1024;       // (A/B builds with other table sizes)
+    if (const char *e = knob("SR_STATIC_LDS_KB")) lds_static = (size_t)std::max(1, atoi(e)) * 1024;       // (A/B builds with other table sizes)
     const size_t lds_per_wg = c->lds_bytes + lds_static;
     pl.wg_per_cu = (int)std::min<size_t>((size_t)pl.wg_per_cu, std::max<size_t>(1, (160 * 1024) / lds_per_wg));
     // long sequences: the four LDS copies leave room for two workgroups per CU (C5: 50 KB each) -- give each 8 waves, or
     // the SIMDs hold two waves (C5 subset 3 507 -> 2 200 ms).  512-thread builds: int16 rows; 32-bit searches with the
     // uint16 ring (exact instance below 57 k, see ring_u16)
-    const char *ru = getenv("SR_RING_U16");
+    const char *ru = knob("SR_RING_U16");
     const bool u16_ok = kblock == 10 && maxlen <= 57000 && !(ru && atoi(ru) == 0);
-    if (impl == 2 && !pl.wave_wg && pl.wg_per_cu <= 2 && !getenv("SR_ALIGN_THREADS") && (c->off16 || u16_ok)) c->nthreads = 512;
+    if (impl == 2 && !pl.wave_wg && pl.wg_per_cu <= 2 && !knob("SR_ALIGN_THREADS") && (c->off16 || u16_ok)) c->nthreads = 512;
     // 32-bit searches below 57 k keep their ring as uint16 (offset + 8192): half the row bytes (C5 is bound by them).
     // The exact 10-level instance at >= 256 threads has that build; SR_RING_U16=0 keeps 32-bit rows.
     pl.ring_u16 = (impl == 2 && !c->off16 && u16_ok && c->nthreads >= 256) ? 1 : 0;
     pl.rsz = pl.ring_u16 ? 2 : pl.osz;                 // bytes per ring cell (the base-case history keeps osz)
     pl.bbase_jobs = pl.wave_wg ? (c->nthreads == 64 ? 4 : 8) : 16;
-    if (const char *e = getenv("SR_BFS_BASE_JOBS")) pl.bbase_jobs = std::max(1, std::min(16, atoi(e)));
+    if (const char *e = knob("SR_BFS_BASE_JOBS")) pl.bbase_jobs = std::max(1, std::min(16, atoi(e)));
     return SR_OK;
 }
 
@@ -690,7 +743,7 @@ static int plan_workspace(const sr_ctx *c, const SrPen &pen, const SrPen &ori, u
     pl.brow = (int)((4 * maxlen + 32 * 72 + 64 + 512 + 7) & ~7ULL);     // per-aligner margins + read slack of the last wave tile
     pl.kdepth = std::max(pen.scope + std::max(kblock, 1), ori.scope + 1) + 1;
     // lazy I/D rows (sr_align_blk.inc blk_recompute): the M rows must reach 2 * scope + 2 blocks back
-    const char *lz = getenv("SR_LAZY_ID");
+    const char *lz = knob("SR_LAZY_ID");
     pl.lazy_id = (impl == 2 && !(lz && atoi(lz) == 0) && 2 * pen.scope + 2 * kblock + 2 <= SR_BLK_MAK_SLOTS) ? 1 : 0;
     pl.kdepth2 = pl.kdepth;
     if (pl.lazy_id) {
@@ -699,11 +752,17 @@ static int plan_workspace(const sr_ctx *c, const SrPen &pen, const SrPen &ori, u
         pl.kdepth2 = std::max(pl.kdepth, pen.scope + 2 * kblock + 2);
         pl.kdepth = std::max(pl.kdepth, 2 * pen.scope + 2 * kblock + 2);
     }
+    if (impl == 2 && kblock == 10) {
+        // exact instance: ring depths are multiples of the block, so that a block's ten levels (and five levels from a multiple
+        // of five) are adjacent rows that never straddle the ring's wrap -- the tile addresses them as base + immediate
+        // (sr_align_blk.inc kbase; default penalties: 74 -> 80 M levels, 48 -> 50 I / D levels)
+        pl.kdepth = (pl.kdepth + 9) / 10 * 10; pl.kdepth2 = (pl.kdepth2 + 9) / 10 * 10;
+    }
     // level-per-pass kernel: M ring | 4 hot I/D rings | cold I/D history | NULL row | U row, rows of brow cells
     pl.bring_wg = ((uint64_t)(pl.ring_scope + 1) + 4ULL * pl.ring_hot + 4ULL * (pl.ring_scope + 1) + 2ULL) * (uint64_t)pl.brow;
     // blocked kernel: chunk-major ring (sr_align_blk.inc KRows): 256-cell pieces of all depth + 4 * depth2 + 3 rows together
     // (NULL, U, trash), + 2 pieces of read slack; a workgroup's rows are addressed as base + 32-bit byte offset
-    if (impl == 2) pl.bring_wg = ((uint64_t)pl.brow / 256 + 2ULL) * ((uint64_t)pl.kdepth + 4ULL * pl.kdepth2 + 3ULL) * 256ULL + 1024;
+    if (impl == 2) pl.bring_wg = ((uint64_t)pl.brow / 256 + 2ULL) * ((uint64_t)pl.kdepth + 4ULL * pl.kdepth2 + (uint64_t)SR_NULL_ROWS + 2ULL) * 256ULL + 1024;
     if (impl == 2 && pl.bring_wg * pl.rsz >= (1ULL << 32)) return fail(SR_ERR_UNSUPPORTED, "sequences too long for the device row workspace (4 GB per workgroup)");
     // base-case history.  Level-per-pass kernel: bbase_jobs fixed slots of the worst-case width.  Blocked kernel: hist_cap
     // cells in which every job of a batch gets a region for the levels and width it really needs (sr_align_blk.inc); one
@@ -711,7 +770,7 @@ static int plan_workspace(const sr_ctx *c, const SrPen &pen, const SrPen &ori, u
     // ~150 need 6.5 M cells and still run as one batch; SR_HIST_JOBS=n: n of them)
     const uint64_t hist_worst = (uint64_t)pl.hist_levels * 5 * (uint64_t)pl.hist_w;
     pl.hist_cap = hist_worst * 4;
-    if (const char *e = getenv("SR_HIST_JOBS")) pl.hist_cap = hist_worst * (uint64_t)std::max(1, std::min(16, atoi(e)));
+    if (const char *e = knob("SR_HIST_JOBS")) pl.hist_cap = hist_worst * (uint64_t)std::max(1, std::min(16, atoi(e)));
     pl.hist_nul_w = impl == 2 ? (uint64_t)pl.hist_w + 256 : (uint64_t)pl.bbase_jobs * (uint64_t)pl.hist_w;
     pl.bhist_wg = impl == 2 ? ((pl.hist_cap + pl.hist_nul_w + 256 + 1024 + 7) & ~7ULL)      // data, NULL row, trash cells, slack
                             : ((uint64_t)pl.hist_levels * 5 + 1) * pl.hist_nul_w + 1024;
@@ -735,7 +794,7 @@ static int plan_memory(sr_ctx *c, uint32_t np, Plan &pl) {
     pl.arena_ops = c->cigar_base[np] + 1;
     {
         uint64_t cap = std::max<uint64_t>((uint64_t)(avail * 0.25) / 4, pl.max_reserve + 1);
-        if (const char *e = getenv("SR_CIGAR_ARENA_OPS")) cap = std::max<uint64_t>((uint64_t)atoll(e), pl.max_reserve + 1);   // (tests: force batches)
+        if (const char *e = knob("SR_CIGAR_ARENA_OPS")) cap = std::max<uint64_t>((uint64_t)atoll(e), pl.max_reserve + 1);   // (tests: force batches)
         pl.arena_ops = std::min(pl.arena_ops, cap);
     }
     if (pl.arena_ops * 4 > avail / 2) return fail(SR_ERR_NOMEM, "not enough device memory for one pair's CIGAR");
@@ -749,7 +808,7 @@ static int plan_memory(sr_ctx *c, uint32_t np, Plan &pl) {
     pl.left = avail - pl.arena_ops * 4;
     const uint64_t budget = (uint64_t)(pl.left * 0.7);
     int nwg = pl.cus * pl.wg_per_cu;
-    if (const char *e = getenv("SR_NWG")) nwg = std::max(1, std::min(nwg, atoi(e)));   // (tests: several pairs per workgroup on a small input)
+    if (const char *e = knob("SR_NWG")) nwg = std::max(1, std::min(nwg, atoi(e)));   // (tests: several pairs per workgroup on a small input)
     if ((uint64_t)nwg > pl.max_batch_pairs) nwg = (int)pl.max_batch_pairs;
     if (nwg < 1) nwg = 1;
     while (nwg > 1 && (uint64_t)nwg * pl.per_wg_bytes > budget) nwg--;
@@ -798,9 +857,9 @@ static int alloc_workspace(sr_ctx *c, const sr_params *p, const PackedSeqs &pk, 
     if ((r = dev_alloc(c, &d, (uint64_t)nwg * pl.bring_wg * rsz))) return r; a.bring = d;
     if ((r = dev_alloc(c, &d, (uint64_t)nwg * pl.bhist_wg * osz))) return r; a.bhist = d;
     // (tests: the kernels must not depend on what the row workspaces held before -- poison them with plausible offsets)
-    if (const char *e = getenv("SR_POISON_ROWS")) {
+    if (const char *e = knob("SR_POISON_ROWS")) {
         const int v = atoi(e);
-        if (rsz == 2) HIPCHK(hipMemsetD16Async((hipDeviceptr_t)a.bring, (unsigned short)(pl.ring_u16 ? v + 8192 : v), (size_t)nwg * pl.bring_wg, c->stream));
+        if (rsz == 2) HIPCHK(hipMemsetD16Async((hipDeviceptr_t)a.bring, (unsigned short)(pl.ring_u16 ? v - 24576 : v), (size_t)nwg * pl.bring_wg, c->stream));
         else HIPCHK(hipMemsetD32Async((hipDeviceptr_t)a.bring, v, (size_t)nwg * pl.bring_wg, c->stream));
         if (osz == 2) HIPCHK(hipMemsetD16Async((hipDeviceptr_t)a.bhist, (unsigned short)v, (size_t)nwg * pl.bhist_wg, c->stream));
         else HIPCHK(hipMemsetD32Async((hipDeviceptr_t)a.bhist, v, (size_t)nwg * pl.bhist_wg, c->stream));
@@ -813,7 +872,7 @@ static int alloc_workspace(sr_ctx *c, const sr_params *p, const PackedSeqs &pk, 
     // Worth it when there are enough pairs to fill the chip with one wave each and the three sequence copies of a
     // wave leave >= 8 waves per CU (measured: C2 / C4 faster; C3 -- 144 pairs -- 1.6x and C5 -- 50 kb, 4 waves per
     // CU by LDS -- 9 % slower than orientation inside the alignment kernel's workgroup).  SR_PREORIENT=1 / 0 forces.
-    const char *po = getenv("SR_PREORIENT");
+    const char *po = knob("SR_PREORIENT");
     const bool pre_auto = (uint64_t)np >= 4ULL * (uint64_t)pl.cus && (size_t)pl.max_words * 12 <= 20 * 1024;
     if (impl == 2 && (po ? atoi(po) != 0 : pre_auto) && (size_t)pl.max_words * 12 <= 60 * 1024) {
         const int orow = (int)((2 * ((2 * maxlen + 32) & ~3ULL) + 512 + 7) & ~7ULL);
@@ -825,7 +884,7 @@ static int alloc_workspace(sr_ctx *c, const sr_params *p, const PackedSeqs &pk, 
             if ((r = dev_alloc(c, &d, pl.oring_bytes))) return r; a.oring = d;
             if ((r = dev_alloc(c, &d, sizeof(uint32_t)))) return r; c->d_oqueue = (uint32_t *)d;
             a.oring_wg_stride = oring_wg; a.orow = orow; a.oqueue = c->d_oqueue; a.pre_oriented = 1;
-            if (!getenv("SR_NO_REORDER")) {       // dequeue order from the orientation scores, per batch
+            if (!knob("SR_NO_REORDER")) {       // dequeue order from the orientation scores, per batch
                 c->otemp_bytes = srk_order_temp_bytes(pl.max_batch_pairs);
                 if ((r = dev_alloc(c, &d, (uint64_t)pl.max_batch_pairs * 8))) return r; c->d_okeys = (uint64_t *)d;
                 if ((r = dev_alloc(c, &d, (uint64_t)pl.max_batch_pairs * 8))) return r; c->d_okeys2 = (uint64_t *)d;
@@ -856,16 +915,17 @@ static int alloc_workspace(sr_ctx *c, const sr_params *p, const PackedSeqs &pk, 
     a.queue_head = c->d_queue; a.pen = pen; a.ori = ori; a.mem_mode = p->memory_mode;
     a.ring_scope = pl.ring_scope; a.ring_hot = pl.ring_hot;
     a.hist_w = pl.hist_w; a.hist_levels = pl.hist_levels;
-    { const char *pt_ = getenv("SR_PROFILE_TICKS"); a.profile_ticks = (pt_ && atoi(pt_) != 0) ? 1 : 0; }
+    { const char *pt_ = knob("SR_PROFILE_TICKS"); a.profile_ticks = (pt_ && atoi(pt_) != 0) ? 1 : 0; }
     a.impl = impl; a.kdepth = pl.kdepth; a.kdepth2 = pl.kdepth2; a.kblock = pl.kblock; a.lazy_id = pl.lazy_id; a.ring_u16 = pl.ring_u16;
-    a.ori_levels = getenv("SR_ORIENT_LEVELS") ? 1 : 0;
+    a.ori_levels = knob("SR_ORIENT_LEVELS") ? 1 : 0;
+    { const char *tb = knob("SR_TEST_BASE_LEVELS"); a.test_base_levels = tb ? std::max(0, atoi(tb)) : 0; }
     a.bring_wg_stride = pl.bring_wg; a.brow = pl.brow; a.bhist_wg_stride = pl.bhist_wg; a.bbase_jobs = pl.bbase_jobs;
     a.hist_cap = pl.hist_cap; a.hist_nul_w = (uint32_t)pl.hist_nul_w; a.hist_stride = (uint32_t)((uint64_t)pl.bbase_jobs * (uint64_t)pl.hist_w);
     a.cigar_base = c->d_cbase; a.counters = c->d_counters; a.error_flag = c->d_error;
     // 8-mer sets of the sequences (8 KB each) for the orientation kernel's lower bound of the reverse orientation's score:
     // plain ACGT buffers, default orientation penalties (the blocked orientation kernel), at most 256 MB and 5 % of what
     // is left.  SR_NO_KBITS=1 switches the bound off (both orientations in lockstep from level 0, as before round 3).
-    if (a.pre_oriented && pk.sm.bits == 2 && !ori.two && ori.x == 1 && ori.o1 == 1 && ori.e1 == 1 && !getenv("SR_NO_KBITS") && !getenv("SR_ORIENT_LEVELS")) {
+    if (a.pre_oriented && pk.sm.bits == 2 && !ori.two && ori.x == 1 && ori.o1 == 1 && ori.e1 == 1 && !knob("SR_NO_KBITS") && !knob("SR_ORIENT_LEVELS")) {
         const uint64_t kb = (uint64_t)c->len.size() * 8192ull;
         if (kb > 0 && kb <= (256ull << 20) && kb <= (uint64_t)(pl.left * 0.05)) {
             if ((r = dev_alloc(c, &d, kb))) return r;
@@ -885,19 +945,20 @@ static int alloc_workspace(sr_ctx *c, const sr_params *p, const PackedSeqs &pk, 
 
 static void write_report(sr_ctx *c, const PackedSeqs &pk, const SrPen &pen, const Plan &pl) {
     const uint32_t np = (uint32_t)c->pair_q.size();
-    char buf[1100];
+    char buf[1400];
     snprintf(buf, sizeof(buf),
              "{\"pairs\": %u, \"batches\": %u, \"symbol_bits\": %d, \"offset_bytes\": %zu, \"ring_cell_bytes\": %zu, \"kernel_impl\": %d, "
              "\"block_levels\": %d, \"two_piece\": %d, \"lazy_id_rows\": %d, \"workgroups\": %d, "
              "\"threads_per_workgroup\": %d, \"workgroups_per_cu\": %d, \"lds_dynamic_bytes\": %zu, \"ring_bytes_per_workgroup\": %llu, "
              "\"base_history_bytes_per_workgroup\": %llu, \"workspace_bytes\": %llu, \"cigar_arena_bytes\": %llu, "
-             "\"orientation_ring_bytes\": %llu, \"union_find_bytes\": %llu, \"device_free_bytes_at_load\": %zu, \"kernel_build\": \"%s\"}",
+             "\"orientation_ring_bytes\": %llu, \"union_find_bytes\": %llu, \"device_free_bytes_at_load\": %zu, \"kernel_build\": \"%s\", "
+             "\"ring_depth_m\": %d, \"ring_depth_id\": %d, \"source_digest\": \"%s\", \"knobs\": ",
              np, pl.nbatch, pk.sm.bits, pl.osz, pl.impl == 2 ? pl.rsz : pl.osz, pl.impl, pl.impl == 2 ? pl.kblock : 1, pen.two ? 1 : 0, pl.lazy_id,
              pl.nwg, c->nthreads, pl.wg_per_cu, c->lds_bytes,
              (unsigned long long)(pl.bring_wg * pl.rsz), (unsigned long long)(pl.bhist_wg * pl.osz),
              (unsigned long long)((uint64_t)pl.nwg * pl.per_wg_bytes), (unsigned long long)(pl.arena_ops * 4), (unsigned long long)pl.oring_bytes,
-             (unsigned long long)(3ULL * c->uf_size * 8), pl.free_b, srk_align_blk_build_tag());
-    c->workspace_report = buf;
+             (unsigned long long)(3ULL * c->uf_size * 8), pl.free_b, srk_align_blk_build_tag(), pl.kdepth, pl.kdepth2, srk_source_digest());
+    c->workspace_report = std::string(buf) + knobs_json() + "}";
 }
 
 static int load_impl(sr_ctx *c, const sr_seqset *seqs, const sr_params *p, const uint32_t *eq, const uint32_t *et,
@@ -1078,14 +1139,24 @@ extern "C" int sr_ctx_sync(sr_ctx *c) {
         int err = 0;
         HIPCHK(hipMemcpy(&err, c->d_error, sizeof(int), hipMemcpyDeviceToHost));
         if (err) {
-            static const char *names[8] = {"score bound exceeded", "base-case history overflow", "backtrace found no predecessor",
+            static const char *names[9] = {"score bound exceeded", "base-case history overflow", "backtrace found no predecessor",
                                            "recursion stack / segment list overflow", "CIGAR buffer overflow", "union-find retry bound",
-                                           "breakpoint outside its segment", "graph induction"};
+                                           "breakpoint outside its segment", "graph induction",
+                                           "row / LDS address outside the workgroup's extent (bounds-checked build)"};
             std::string msg = "device reported internal fault bits";
             char buf[32];
             snprintf(buf, sizeof(buf), " 0x%x:", err);
             msg += buf;
-            for (int b = 0; b < 8; b++) if (err & (1 << b)) { msg += " ["; msg += names[b]; msg += "]"; }
+            for (int b = 0; b < 9; b++) if (err & (1 << b)) { msg += " ["; msg += names[b]; msg += "]"; }
+            if (err & SR_DEV_ERR_ADDRESS) {                  // first offender: counters[40..43] = pair + 1, what, offset, extent
+                uint64_t d[4] = {0, 0, 0, 0};
+                if (hipMemcpy(d, c->d_counters + 40, sizeof(d), hipMemcpyDeviceToHost) == hipSuccess && d[0]) {
+                    char b2[160];
+                    snprintf(b2, sizeof(b2), " first: pair #%llu, %s, offset %llu, extent %llu", (unsigned long long)(d[0] - 1),
+                             d[1] == 1 ? "ring row" : d[1] == 2 ? "history row" : "LDS window", (unsigned long long)d[2], (unsigned long long)d[3]);
+                    msg += b2;
+                }
+            }
             // which pair(s): a failed alignment leaves score -1
             if (!c->from_paf && c->aa.score) {
                 const size_t np = c->pair_q.size();
@@ -1136,8 +1207,17 @@ extern "C" int sr_ctx_counters_ext(sr_ctx *c, uint64_t out[32]) {
     if (!c || !c->loaded) return fail(SR_ERR_INVALID, "context not loaded");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemcpy(out, c->d_counters, SR_NCOUNTERS * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out, c->d_counters, 32 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return SR_OK;
+}
+// every slot the device keeps (SR_NCOUNTERS = 48 since round 4); returns the number of slots written (<= cap) or a negative status
+extern "C" int sr_ctx_counters_all(sr_ctx *c, uint64_t *out, uint32_t cap) {
+    if (!c || !c->loaded || !out) return fail(SR_ERR_INVALID, "context not loaded");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const uint32_t n = std::min<uint32_t>(cap, SR_NCOUNTERS);
+    HIPCHK(hipMemcpy(out, c->d_counters, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return (int)n;
 }
 
 extern "C" int sr_ctx_download_uf(sr_ctx *c, uint64_t *parent_out) {

@@ -12,6 +12,7 @@
 #define SR_BFS_SEGREC 16             // ints per segment record
 #define SR_BFS_MAXACT 32             // segments searched concurrently (2 aligners each)
 #define SR_BFS_BTCAP 1024
+#define SR_NULL_ROWS 10               // NULL rows of the blocked kernel's ring (a whole block of levels below 0, sr_align_blk.inc kbase)
 #define SR_BLK_MAK_SLOTS 80          // ring depth the blocked kernel supports (2 * scope + 2 * block + 2 = 74 for 0,5,8,2,24,1)
 
 enum { SR_C_M = 0, SR_C_I1 = 1, SR_C_I2 = 2, SR_C_D1 = 3, SR_C_D2 = 4 };
@@ -27,7 +28,9 @@ enum {
     SR_DEV_ERR_CIGAR_OVERFLOW = 16,
     SR_DEV_ERR_UF_SPIN = 32,      // union-find retry bound hit
     SR_DEV_ERR_BREAKPOINT = 64,   // breakpoint outside the segment
-    SR_DEV_ERR_GRAPH = 128        // graph induction: strands of a base in different components / hash table full
+    SR_DEV_ERR_GRAPH = 128,       // graph induction: strands of a base in different components / hash table full
+    SR_DEV_ERR_ADDRESS = 256      // bounds-checked build (-DSR_BOUNDS): a row offset outside the workgroup's extent or an LDS window
+                                  // of a live cell outside the staged sequences (the access was not made; counters[40..43])
 };
 
 struct SrPen {
@@ -93,6 +96,8 @@ struct SrAlignArgs {
     int ori_levels;            // impl 2: in-kernel orientation level by level even for the default penalties (SR_ORIENT_LEVELS=1)
     int ring_u16;              // impl 2, 32-bit searches: the ring's cells are uint16 = offset + 8192 (longest sequence < 57 k)
     int *bmak;                 // impl 2: per workgroup [32 aligners][32 ring levels] max M antidiagonal (breakpoint pruning)
+    int test_base_levels;      // impl 2, tests only (SR_TEST_BASE_LEVELS=n): cap on the levels a base case is given at first, so that
+                               //   jobs outgrow their region and take the re-queue path
     // outputs
     uint8_t *is_reverse;       // [npairs]
     int32_t *score;            // [npairs]
@@ -103,7 +108,7 @@ struct SrAlignArgs {
     unsigned long long *counters; // [SR_NCOUNTERS]
     int *error_flag;
 };
-#define SR_NCOUNTERS 32
+#define SR_NCOUNTERS 48
 
 struct SrUniteArgs {
     const uint32_t *pair_q, *pair_t;
@@ -147,6 +152,7 @@ int srk_graph_induce(const unsigned long long *labels, const uint8_t *bases, con
                      uint32_t *steps, uint8_t *node_base, unsigned long long *hkeys, uint32_t *hvals,
                      uint64_t hcap, uint32_t *eslot, unsigned long long *edges, uint32_t *tile_sum,
                      uint32_t *counts, int *error_flag, void *stream);
+const char *srk_source_digest(void);                                 // digest of the sources this library was built from (Makefile, scripts/src_digest.py)
 const char *srk_align_blk_build_tag(void);                         // name of the blocked kernel's build (scripts/build_variant.sh)
 int srk_align_blk_max_levels(void);                                // deepest block of the build (static LDS tables)
 int srk_align_blk_supports(const SrPen *pen, const SrPen *ori);   // levels per block, 0 = no blocked instance

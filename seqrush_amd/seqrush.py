@@ -364,8 +364,11 @@ class Context:
         return float(ms.value)
 
     def counters(self):
-        out = (C.c_uint64 * 32)()
-        check(self.L.sr_ctx_counters_ext(self._h, out))
+        """device counters of the last align / unite (include/seqrush_amd.h sr_ctx_counters_all): every name maps to ONE slot"""
+        out = (C.c_uint64 * 48)()
+        n = self.L.sr_ctx_counters_all(self._h, out, 48)
+        if n < 0:
+            check(n)
         return dict(row_bytes_loaded=int(out[16]), row_bytes_stored=int(out[17]), tk_recompute=int(out[18]),
                     wf_cells=int(out[0]), wf_steps=int(out[1]), base_segments=int(out[2]),
                     breakpoint_searches=int(out[3]), united_bases=int(out[4]), match_runs=int(out[5]),
@@ -374,8 +377,11 @@ class Context:
                     tk_barrier=int(out[12]), tk_setup_first=int(out[13]), tk_phase2=int(out[14]),
                     tk_tail=int(out[15]), bp_filter_units=int(out[19]), bp_candidates=int(out[20]),
                     bp_exact_units=int(out[21]), bp_rounds=int(out[22]), tk_backtrace=int(out[23]), tk_emit=int(out[24]),
-                    st_wait_cycles=int(out[25]), st_body_cycles=int(out[26]), st_tiles=int(out[27]), st_ext_iters=int(out[28]),
-                    tk_ctl_section=int(out[25]), tk_ctl_mak=int(out[26]), tk_ctl_segments=int(out[27]), tk_p2_list=int(out[28]), tk_p2_filter=int(out[29]), tk_p2_exact=int(out[30]), tk_p2_replay=int(out[31]))
+                    tk_ctl_section=int(out[25]), tk_ctl_mak=int(out[26]), tk_ctl_segments=int(out[27]), tk_p2_list=int(out[28]),
+                    tk_p2_filter=int(out[29]), tk_p2_exact=int(out[30]), tk_p2_replay=int(out[31]),
+                    st_wait_cycles=int(out[32]), st_body_cycles=int(out[33]), st_tiles=int(out[34]), st_ext_iters=int(out[35]),
+                    lds_row_bytes=int(out[36]), base_requeues=int(out[37]),
+                    bounds_first=[int(out[40]), int(out[41]), int(out[42]), int(out[43])])
 
     def close(self):
         if self._h:

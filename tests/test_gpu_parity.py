@@ -166,10 +166,11 @@ def test_several_pairs_per_workgroup(gpu, monkeypatch, name, recs, kw, env):
     check_parity(recs, **kw)
 
 
-@pytest.mark.parametrize("length,env", [(40000, {}), (40000, {"SR_RING_U16": "0"}), (60000, {})])
+@pytest.mark.parametrize("length,env", [(40000, {}), (40000, {"SR_RING_U16": "0"}), (56900, {}), (57100, {}), (60000, {})])
 def test_50kb_pair_int32_offsets(gpu, monkeypatch, length, env):
-    """sequences > 32 kb take the 32-bit offset kernel instantiation (LDS staging of 50 kb sequences); below 57 k its
-    ring is stored as uint16 (offset + 8192), above -- or with SR_RING_U16=0 -- as int32"""
+    """sequences > 32 kb take the 32-bit offset kernel instantiation (LDS staging of 50 kb sequences); up to 57 k its
+    ring is 16 bits per cell (offset - 24576, signed: the packed tile runs on the rows as stored), above -- or with
+    SR_RING_U16=0 -- int32; both sides of the 57 000 switch"""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     recs = synth.snp_family(2, length, 0.01 if length <= 40000 else 0.004, 61)
@@ -178,6 +179,22 @@ def test_50kb_pair_int32_offsets(gpu, monkeypatch, length, env):
     assert rep["offset_bytes"] == 4 and rep["ring_cell_bytes"] == (2 if length <= 57000 and not env else 4)
     # the report names the blocked kernel's build: "default" unless SEQRUSH_AMD_LIB points at an A/B library
     assert rep["kernel_build"] == ("default" if not os.environ.get("SEQRUSH_AMD_LIB") else rep["kernel_build"])
+    check_parity(recs)
+
+
+@pytest.mark.parametrize("env", [{}, {"SR_NWG": "1"}, {"SR_NWG": "2", "SR_POISON_ROWS": "37"}])
+def test_16bit_ring_packed_tile_indels_rc_and_ring_reuse(gpu, monkeypatch, env):
+    """the packed tile on the 16-bit ring of 32-bit searches (round 4; C5's instance): 34 kb sequences with indels, an in-place
+    inversion and a reverse-complemented member; one workgroup aligning all pairs one after the other (the ring is reused
+    with whatever the previous pair left in it: tight tile coverage must never read it) and rows poisoned with a
+    plausible offset before the run"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    fam = synth.indel_family_fast(3, 34000, 0.015, 0.002, 5301, max_indel=6)
+    recs = [("a", fam[0][1]), ("inv", synth.invert_segment(fam[1][1], 9000, 2500)), ("rc", synth.reverse_complement(fam[2][1]))]
+    ss = SeqSet(recs); ctx = Context(0); ctx.load(ss, Params())
+    rep = ctx.workspace_report(); ctx.close()
+    assert rep["offset_bytes"] == 4 and rep["ring_cell_bytes"] == 2 and rep["block_levels"] == 10
     check_parity(recs)
 
 
@@ -714,28 +731,91 @@ def test_cpp_cli_binary(gpu, tmp_path):
     assert canon_gfa(out3.read_text()) == canon_gfa(out.read_text())
 
 
-def test_multi_rank_bench_matches_single_rank(gpu):
-    """bench.py's sharded path (pair shard -> per-rank forest -> label all-gather -> replay merge) with 2
-    ranks sharing this GPU over gloo gives the same merged partition as 1 rank"""
+@pytest.mark.parametrize("world,nseq", [(2, 8), (4, 16)])
+def test_multi_rank_bench_matches_single_rank(gpu, world, nseq):
+    """bench.py's sharded path (pair shard -> per-rank forest -> label all-gather -> replay merge) with 2 and with 4
+    ranks sharing this GPU over gloo gives the same merged partition as 1 rank.  The command is the SCALE driver's shape
+    (`python bench.py --gpus N --config C2 ...` started plainly; bench.py launches its own ranks) with
+    SR_BENCH_SINGLE_DEVICE=1; 4 ranks because the GPU box allows 6 processes on the card and this test process and the
+    torch.distributed.run agent are two of them (5 ranks were killed by the pool's process guard in round 4; 8 on one
+    card cannot run here)."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SR_BENCH_LABEL_SHA="1")
-    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--nseq", "8", "--steps", "1", "--warmup", "0",
-                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "C2", "--nseq", str(nseq), "--steps", "1", "--warmup", "0",
+                          "--no-cpu-baseline", "--no-h2h", "--no-host-stages"], capture_output=True, text=True, timeout=600, env=env)
     assert one.returncode == 0, one.stderr[-2000:]
     d1 = json.loads(one.stdout.strip().split("\n")[-1])
     env["SR_BENCH_SINGLE_DEVICE"] = "1"
     # started plainly, the way the driver starts `--gpus 1`: bench.py launches its own ranks as a child process
-    two = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--nseq", "8", "--steps", "1",
+    two = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--config", "C2", "--nseq", str(nseq), "--steps", "1",
                           "--warmup", "0", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
     assert two.returncode == 0, two.stderr[-2000:]
     d2 = json.loads(two.stdout.strip().split("\n")[-1])
-    assert d2["n_gpus"] == 2 and d2["config"]["pairs_per_gpu"] == 32
+    assert d2["n_gpus"] == world and d2["config"]["pairs_total"] == nseq * nseq
+    assert abs(d2["config"]["pairs_per_gpu"] - nseq * nseq / world) <= nseq           # cost-balanced shard of rank 0
     assert d1["labels_sha256"] == d2["labels_sha256"]
     for d in (d1, d2):
         assert d["metric"].startswith("aligned pairs/sec") and d["unit"] == "pairs/s" and "roofline" in d
+
+
+def test_base_case_requeue_when_a_job_outgrows_its_levels(gpu, monkeypatch):
+    """a base case that would run past the levels it was given is stopped before the block that would leave
+    its history region and searched again, alone at the head of the next batch, with the worst-case region -- instead of
+    raising SR_DEV_ERR_BASE_OVERFLOW (or writing into its neighbours).  SR_TEST_BASE_LEVELS=20 gives every job two
+    blocks at first, so most of them take that path: results stay the oracle's, and the counter shows the path ran."""
+    recs = synth.indel_family(4, 1500, 0.04, 0.02, 4711)
+    monkeypatch.setenv("SR_TEST_BASE_LEVELS", "20")
+    al, labels, cnt = check_parity(recs)
+    assert cnt["base_requeues"] > 0
+    ss = SeqSet(recs); ctx = Context(0); ctx.load(ss, Params())
+    assert ctx.workspace_report()["knobs"] == {"SR_TEST_BASE_LEVELS": "20"}          # a measurement names every knob it ran with
+    ctx.close()
+    monkeypatch.delenv("SR_TEST_BASE_LEVELS")
+    _, _, cnt0 = check_parity(recs)
+    assert cnt0["base_requeues"] == 0
+
+
+def test_deep_levels_reset_creeping_nulls(gpu):
+    """searches deeper than SR_DEEP_INT16 = 3 000 levels (sr_align_blk.inc q4_renull): a 12 kb pair at 13 % substitutions +
+    indels (score ~ 17 000: 8 600 levels either side, past the ~4 800 at which a creeping NULL would turn valid) and two
+    unrelated 5 kb sequences (nothing but mismatches and gaps) -- the packed tile's NULLs creep
+    on diagonals that have left the matrix and are reset where a block takes its chains up; CIGARs, scores, partition and
+    GFA equal the oracle's"""
+    fam = synth.indel_family(2, 12000, 0.13, 0.01, 7301)
+    al, labels, cnt = check_parity(fam)
+    assert max(int(x) for x in al.score) > 15000
+    a = synth.to_bytes(synth.base_sequence(5000, 7302)); b = synth.to_bytes(synth.base_sequence(5000, 7303))
+    al, labels, cnt = check_parity([("a", a), ("b", b)])
+    assert max(int(x) for x in al.score) > 8000
+
+
+def test_bounds_checked_build_when_present(gpu, monkeypatch):
+    """the -DSR_BOUNDS instance of the blocked kernel (scripts/build_variant.sh bounds "-DSR_BOUNDS=1"), when it was built:
+    every row access tested against the workgroup's extent, every LDS window of a live cell against the staged sequences --
+    a C2 subset, a family with indels and reverse complements and several pairs per workgroup run clean (no
+    SR_DEV_ERR_ADDRESS) and equal the oracle.  A subprocess, because the library is chosen at load time."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "seqrush_amd", "libseqrush_amd_bounds.so")
+    if not os.path.exists(lib):
+        pytest.skip("libseqrush_amd_bounds.so not built (scripts/build_variant.sh bounds \"-DSR_BOUNDS=1\")")
+    code = ("import sys; sys.path.insert(0, 'tests'); import test_gpu_parity as t; from seqrush_amd import synth\n"
+            "from seqrush_amd.seqrush import SeqSet, Params, Context\n"
+            "ss = SeqSet(synth.config_c2(8)); c = Context(0); c.load(ss, Params()); assert c.workspace_report()['kernel_build'] == 'bounds'; c.close()\n"
+            "t.check_parity(synth.config_c2(8))\n"
+            "t.check_parity([(n, synth.reverse_complement(s) if i == 2 else s) for i, (n, s) in enumerate(synth.indel_family(5, 2500, 0.04, 0.02, 99))])\n"
+            "t.check_parity(synth.indel_family(2, 12000, 0.13, 0.01, 7301))\n"
+            "print('bounds build clean')\n")
+    for nwg in ("", "2"):
+        env = dict(os.environ, SEQRUSH_AMD_LIB=lib)
+        if nwg:
+            env["SR_NWG"] = nwg
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "bounds build clean" in r.stdout, (r.stdout[-800:], r.stderr[-1500:])
 
 
 # --------------------------------------------------------------------------- round 2: raw-byte alphabets
