@@ -445,12 +445,19 @@ def main():
         if rec:
             roof["traffic"] = rec["traffic"]
         # `bound`: whichever resource of THIS run sits closest to its ceiling.  hbm: device-counted rows / time against
-        # the 8 TB/s peak (and against the 6.3 TB/s a streaming copy sustains, MI355X_MICROARCH.md); issue: the recorded
+        # the 8 TB/s peak (and against the 6.3 TB/s a streaming copy sustains, MI355X_MICROARCH.md), or -- when a PMC pass of
+        # this kernel is on record -- the traffic it measured behind the L2, whichever is larger; issue: the recorded
         # VALU-issue fraction against the 0.39 wave-instructions / cycle / SIMD four resident integer waves attain
         # (scripts/calib) -- known only from a PMC pass, so it takes part only when `recorded` matches this
         # kernel; a kernel near neither ceiling whose waves are parked (s_waitcnt / barriers) is "latency".
         closeness = {"hbm": rows_GBps / HBM_PEAK_GBS}
         basis = {"hbm_frac_of_peak": rows_GBps / HBM_PEAK_GBS, "hbm_frac_of_streaming_copy_6300": rows_GBps / 6300.0}
+        if rec and rec.get("traffic_GBps"):
+            # what the memory system behind the L2 carried (DRAM-destined requests incl. Infinity-Cache hits: gfx950 has no
+            # counter that separates them), from the recorded PMC pass at ITS kernel time
+            basis["recorded_traffic_frac_of_peak"] = rec["traffic_GBps"] / HBM_PEAK_GBS
+            basis["recorded_traffic_frac_of_streaming_copy_6300"] = rec["traffic_GBps"] / 6300.0
+            closeness["hbm"] = max(closeness["hbm"], rec["traffic_GBps"] / HBM_PEAK_GBS)
         if rec and rec.get("valu_issue_frac") is not None:
             basis["valu_issue_frac_of_peak_0.5"] = rec["valu_issue_frac"]
             basis["valu_issue_frac_of_attainable_0.39"] = rec["valu_issue_frac"] * 0.5 / 0.39
