@@ -464,9 +464,14 @@ def main():
             basis["wait_any_frac"] = rec.get("wait_any_frac")
             closeness["valu-issue"] = rec["valu_issue_frac"] * 0.5 / 0.39
         top = max(closeness, key=closeness.get)
-        if closeness[top] < 0.5 and (rec is None or (rec.get("wait_any_frac") or 0) >= 0.4):
-            basis["note"] = "no resource above half its ceiling: the waves wait (dependent LDS / row round trips, barriers, one-wave sections)"
-            roof["bound"] = "latency" if rec else top
+        # nothing within a quarter of its ceiling while the waves are parked in s_waitcnt / barriers for >= 45 % of their
+        # resident cycles: the kernel is bound by the latency of its dependent steps (LDS round trips of the extension, row
+        # round trips, barriers, one-wave sections), not by a throughput ceiling.  (Round-4 A/B runs agree: -8 % instructions
+        # in the tile: +-0; -9 % row bytes: +-0; -6 % tiles: -2.4 %.  DESIGN.md section 6.1.)
+        if closeness[top] < 0.75 and rec is not None and (rec.get("wait_any_frac") or 0) >= 0.45:
+            basis["note"] = ("no resource within a quarter of its ceiling and the waves parked %.0f %% of their cycles: latency of dependent "
+                             "steps; closest ceiling: %s at %.2f" % (100.0 * rec["wait_any_frac"], top, closeness[top]))
+            roof["bound"] = "latency"
         else:
             roof["bound"] = top
         roof["bound_basis"] = basis
