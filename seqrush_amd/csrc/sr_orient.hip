@@ -207,9 +207,33 @@ __global__ void __launch_bounds__(64, 4) sr_orient_blk_kernel(SrAlignArgs a) {
             for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
             lb_rev = (npos - cnt + 7) / 8;
         }
+        // Upper bound of the forward orientation's score: the alignment along diagonal 0 (one mismatch per differing
+        // column) closed by one gap over the length difference (1 + length under the orientation penalties).  Below the
+        // reverse orientation's lower bound the forward one wins whatever the two scores are exactly -- the reverse
+        // complement is chosen only at a strictly lower score -- and neither aligner runs; ori_fwd then holds the bound
+        // (it only orders the queue).  Substitution-only families (C2, C4) decide almost every pair here.
+        bool decided = false;
+        if (lb_rev > 0) {
+            const int n = min(plen, tlen), nw = (n + 15) >> 4;
+            const LP Pf = (LP)(lds_seq + 1);
+            int ham = 0;
+            for (int i = lane; i < nw; i += 64) {
+                uint32_t x = Pf[i] ^ T[i];
+                x = (x | (x >> 1)) & 0x55555555u;
+                const int rem = n - (i << 4);
+                if (rem < 16) x &= (1u << (rem << 1)) - 1u;
+                ham += __popc(x);
+            }
+            for (int o = 32; o > 0; o >>= 1) ham += __shfl_xor(ham, o, 64);
+            const int ub = ham + (plen != tlen ? 1 + abs(plen - tlen) : 0);
+            if (ub < lb_rev) { fwd = ub; decided = true; }
+        }
 #endif
         bool rev_on = lb_rev <= 0, catching = false;
         int s0_main = 0, s0_catch = 0;
+#if SR_SYMBITS == 2
+        if (!decided)
+#endif
         for (;;) {
             if (!catching && !rev_on && s0_main + OB - 1 >= lb_rev) {
                 if (s0_main > 0) { catching = true; s0_catch = 0; } else rev_on = true;

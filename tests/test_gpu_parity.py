@@ -569,7 +569,9 @@ def test_orientation_bound_regimes(gpu, nokbits, monkeypatch):
     lets it catch up when the forward one has not finished by then; SR_NO_KBITS=1 runs both from level 0.  Same strands,
     orientation scores and alignments either way and as the oracle, in all three regimes: near-identical sequences (the
     reverse aligner never runs), divergent ones (the bound is below the forward score: catch-up, then lockstep),
-    reverse-complemented members (the reverse aligner wins), plus sequences shorter than a k-mer"""
+    reverse-complemented members (the reverse aligner wins), plus sequences shorter than a k-mer.  Round 4: a pair whose
+    diagonal-0 alignment (mismatches + one end gap) already scores below the reverse bound is decided without either
+    aligner -- the near-identical family and its end-truncated copies count no orientation cells at all"""
     monkeypatch.setenv("SR_PREORIENT", "1")
     if nokbits:
         monkeypatch.setenv("SR_NO_KBITS", nokbits)
@@ -577,10 +579,13 @@ def test_orientation_bound_regimes(gpu, nokbits, monkeypatch):
     far = synth.snp_family(4, 1800, 0.16, 7712)
     mixed = synth.snp_family(6, 1500, 0.05, 7713, rc_every=2) + [("tiny", b"ACGTA"), ("k", b"ACGTTGCAAC")]
     outs = []
-    for recs in (near, far, mixed):
+    trunc = [(n, s[:len(s) - 9 * i]) for i, (n, s) in enumerate(near)]
+    for recs in (near, far, mixed, trunc):
         al, _, cnt = check_parity(recs)
         outs.append((al.is_reverse.copy(), al.score.copy()))
-    assert not outs[0][0].any() and not outs[1][0].any() and outs[2][0].any()
+        if not nokbits and recs in (near, trunc):
+            assert cnt["ticks_orientation"] == 0, cnt["ticks_orientation"]
+    assert not outs[0][0].any() and not outs[1][0].any() and outs[2][0].any() and not outs[3][0].any()
     ss = SeqSet(near); ctx = Context(0); ctx.load(ss, Params()); ctx.align(); ctx.sync()
     cells = ctx.counters()["ticks_orientation"]               # (pre-oriented runs: the orientation kernel's cells)
     ctx.close()
