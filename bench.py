@@ -418,11 +418,18 @@ def main():
                 "wf_cells_per_s": cells_8d / sec if sec > 0 else None,
                 "level_diagonals_per_s": ldiag / sec if sec > 0 else None,
                 "orient_kernel_ms": o_ms, "orient_level_diagonals": ori_cells,
-                "unite": {"kernel": "sr_unite_kernel", "kernel_ms": u_ms, "united_bases": cnt["united_bases"],
-                          "bytes": cnt["united_bases"] * 24,
-                          "achieved": cnt["united_bases"] * 24 / (u_ms * 1e-3) / 1e9 if u_ms > 0 else None,
-                          "unit": "GB/s", "bound": "hbm (random access, atomics)",
-                          "frac": cnt["united_bases"] * 24 / (u_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if u_ms > 0 else None}}
+                "unite": None}
+        if rep.get("fused_unite"):
+            # since round 4 the blocked alignment kernel unites a pair's match runs right after its CIGAR (sr_ctx_run):
+            # no unite kernel, its atomics are inside roofline.kernel_ms
+            roof["unite"] = {"kernel": None, "fused_into": ctx.align_kernel, "kernel_ms": 0.0,
+                             "united_bases": cnt["united_bases"], "bytes": cnt["united_bases"] * 24}
+        else:
+            roof["unite"] = {"kernel": "sr_unite_kernel", "kernel_ms": u_ms, "united_bases": cnt["united_bases"],
+                             "bytes": cnt["united_bases"] * 24,
+                             "achieved": cnt["united_bases"] * 24 / (u_ms * 1e-3) / 1e9 if u_ms > 0 else None,
+                             "unit": "GB/s", "bound": "hbm (random access, atomics)",
+                             "frac": cnt["united_bases"] * 24 / (u_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if u_ms > 0 else None}
         # PMC passes cannot run inside this process: the newest recorded summary (profiles/rNN_counters.json, written by
         # scripts/profile_round.sh) is attached under ONE object, `recorded`, and only when it was taken for this kernel
         # name on this workload; it carries the kernel time, box and commit it was measured at

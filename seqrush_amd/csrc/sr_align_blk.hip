@@ -1,5 +1,6 @@
 // sr_align_blk.hip -- translation unit of the score-blocked, wave-tiled biWFA kernel (see sr_align_blk.inc)
 #include "sr_dev_common.h"
+#include "sr_uf_dev.h"
 #define SR_BLK_TU 1
 #undef SR_BFS_MAXACT
 #ifdef SR_BLK_WAVE

@@ -46,6 +46,7 @@ static const SrKnob SR_KNOBS[] = {
     {"SR_NO_REORDER", "off", "keep list order instead of the cost-sorted dequeue order"},
     {"SR_ORIENT_LEVELS", "off", "orientation level by level even for the default penalties"},
     {"SR_NO_KBITS", "off", "no q-gram bound in the orientation kernel"},
+    {"SR_NO_FUSED_UNITE", "off", "sr_ctx_run launches sr_unite_kernel per batch instead of uniting inside the blocked alignment kernel"},
     {"SR_PROFILE_TICKS", "0", "1 = launch the instrumented instance (100 MHz tick counters)"},
     {"SR_FORCE_INT32", "off", "tests: 32-bit offsets (and the 16-bit ring of 32-bit searches) whatever the sequence length"},
     {"SR_TEST_BASE_LEVELS", "off", "tests: cap on the levels a base case is given at first (forces the re-queue path)"},
@@ -261,6 +262,7 @@ struct sr_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[5];
     int ev_used[5] = {0, 0, 0, 0, 0};
     bool loaded = false;
+    bool fuse_unite = false;           // sr_ctx_run: the blocked alignment kernel unites each pair after its CIGAR (no unite kernel)
     bool from_paf = false;             // loaded by sr_ctx_load_paf: no alignment stage, no sr_alignments
     bool aligned_batch_valid = false;  // the arena holds the CIGARs of the last batch sr_ctx_align ran
     std::string workspace_report;      // sizing of the last load (sr_ctx_workspace_report)
@@ -936,6 +938,8 @@ static int alloc_workspace(sr_ctx *c, const sr_params *p, const PackedSeqs &pk, 
     SrUniteArgs &u = c->ua;
     memset(&u, 0, sizeof(u));
     u.pair_q = d_pq; u.pair_t = d_pt; u.npairs = np; u.seqlen = sd.len; u.seq_goff = sd.goff;
+    a.fuse_unite = 0; a.uf_nodes = c->d_nodes; a.seq_goff = sd.goff; a.max_score = c->d_max_score; a.min_match_len = p->min_match_len;
+    c->fuse_unite = impl == 2 && !knob("SR_NO_FUSED_UNITE");
     u.is_reverse = a.is_reverse; u.score = a.score; u.max_score = c->d_max_score;
     u.cigar_ops = a.cigar_ops; u.cigar_base = c->d_cbase; u.cigar_cnt = a.cigar_cnt;
     u.min_match_len = p->min_match_len; u.nodes = c->d_nodes; u.uf_size = c->uf_size;
@@ -945,19 +949,19 @@ static int alloc_workspace(sr_ctx *c, const sr_params *p, const PackedSeqs &pk, 
 
 static void write_report(sr_ctx *c, const PackedSeqs &pk, const SrPen &pen, const Plan &pl) {
     const uint32_t np = (uint32_t)c->pair_q.size();
-    char buf[1400];
+    char buf[1500];
     snprintf(buf, sizeof(buf),
              "{\"pairs\": %u, \"batches\": %u, \"symbol_bits\": %d, \"offset_bytes\": %zu, \"ring_cell_bytes\": %zu, \"kernel_impl\": %d, "
              "\"block_levels\": %d, \"two_piece\": %d, \"lazy_id_rows\": %d, \"workgroups\": %d, "
              "\"threads_per_workgroup\": %d, \"workgroups_per_cu\": %d, \"lds_dynamic_bytes\": %zu, \"ring_bytes_per_workgroup\": %llu, "
              "\"base_history_bytes_per_workgroup\": %llu, \"workspace_bytes\": %llu, \"cigar_arena_bytes\": %llu, "
              "\"orientation_ring_bytes\": %llu, \"union_find_bytes\": %llu, \"device_free_bytes_at_load\": %zu, \"kernel_build\": \"%s\", "
-             "\"ring_depth_m\": %d, \"ring_depth_id\": %d, \"source_digest\": \"%s\", \"knobs\": ",
+             "\"ring_depth_m\": %d, \"ring_depth_id\": %d, \"fused_unite\": %d, \"source_digest\": \"%s\", \"knobs\": ",
              np, pl.nbatch, pk.sm.bits, pl.osz, pl.impl == 2 ? pl.rsz : pl.osz, pl.impl, pl.impl == 2 ? pl.kblock : 1, pen.two ? 1 : 0, pl.lazy_id,
              pl.nwg, c->nthreads, pl.wg_per_cu, c->lds_bytes,
              (unsigned long long)(pl.bring_wg * pl.rsz), (unsigned long long)(pl.bhist_wg * pl.osz),
              (unsigned long long)((uint64_t)pl.nwg * pl.per_wg_bytes), (unsigned long long)(pl.arena_ops * 4), (unsigned long long)pl.oring_bytes,
-             (unsigned long long)(3ULL * c->uf_size * 8), pl.free_b, srk_align_blk_build_tag(), pl.kdepth, pl.kdepth2, srk_source_digest());
+             (unsigned long long)(3ULL * c->uf_size * 8), pl.free_b, srk_align_blk_build_tag(), pl.kdepth, pl.kdepth2, c->fuse_unite ? 1 : 0, srk_source_digest());
     c->workspace_report = std::string(buf) + knobs_json() + "}";
 }
 
@@ -1029,6 +1033,7 @@ static void batch_args(const sr_ctx *c, uint32_t b, SrAlignArgs *a, SrUniteArgs 
         *a = c->aa;
         a->pair_q += f; a->pair_t += f; a->npairs = cnt; if (a->order) a->order += f;
         a->is_reverse += f; a->score += f; a->ori_fwd += f; a->ori_rev += f; a->cigar_cnt += f;
+        if (a->max_score) a->max_score += f;
         a->cigar_base = c->d_cbase + f + b;
     }
     if (u) {
@@ -1039,9 +1044,10 @@ static void batch_args(const sr_ctx *c, uint32_t b, SrAlignArgs *a, SrUniteArgs 
     }
 }
 
-static int enqueue_align_batch(sr_ctx *c, uint32_t b) {
+static int enqueue_align_batch(sr_ctx *c, uint32_t b, bool fuse_unite = false) {
     SrAlignArgs a;
     batch_args(c, b, &a, nullptr);
+    a.fuse_unite = fuse_unite ? 1 : 0;
     HIPCHK(hipMemsetAsync(c->d_queue, 0, sizeof(uint32_t), c->stream));
     hipEvent_t *e0, *e1;
     int r;
@@ -1069,14 +1075,14 @@ static int enqueue_align_batch(sr_ctx *c, uint32_t b) {
     return SR_OK;
 }
 
-static int enqueue_unite_batch(sr_ctx *c, uint32_t b) {
+static int enqueue_unite_batch(sr_ctx *c, uint32_t b, bool fused = false) {
     SrUniteArgs u;
     batch_args(c, b, nullptr, &u);
     hipEvent_t *e0, *e1;
     int r;
     if ((r = ev_get(c, 1, c->ev_used[1], &e0, &e1))) return r;
     HIPCHK(hipEventRecord(*e0, c->stream));
-    if (u.npairs > 0) {
+    if (u.npairs > 0 && !fused) {                  // (fused: the alignment kernel did it; the empty event pair keeps kernel_ms(1) defined)
         int nwg = (int)std::min<uint64_t>(u.npairs, 4096);
         r = srk_unite(&u, nwg, c->stream);
         if (r) return fail(SR_ERR_HIP, std::string("unite kernel launch failed: ") + hipGetErrorString((hipError_t)r));
@@ -1123,9 +1129,10 @@ extern "C" int sr_ctx_run(sr_ctx *c) {
     if (r) return r;
     c->ev_used[1] = 0;
     const uint32_t nbatch = (uint32_t)c->batch_first.size() - 1;
+    const bool fuse = c->fuse_unite && !c->from_paf;
     for (uint32_t b = 0; b < nbatch; b++) {
-        if (!c->from_paf && (r = enqueue_align_batch(c, b))) return r;
-        if ((r = enqueue_unite_batch(c, b))) return r;
+        if (!c->from_paf && (r = enqueue_align_batch(c, b, fuse))) return r;
+        if ((r = enqueue_unite_batch(c, b, fuse))) return r;
     }
     c->aligned_batch_valid = nbatch == 1 && !c->from_paf;
     return SR_OK;

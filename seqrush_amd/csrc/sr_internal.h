@@ -98,6 +98,13 @@ struct SrAlignArgs {
     int *bmak;                 // impl 2: per workgroup [32 aligners][32 ring levels] max M antidiagonal (breakpoint pruning)
     int test_base_levels;      // impl 2, tests only (SR_TEST_BASE_LEVELS=n): cap on the levels a base case is given at first, so that
                                //   jobs outgrow their region and take the re-queue path
+    // impl 2, sr_ctx_run: the workgroup unites the bases of a pair's match runs right after it emitted the CIGAR
+    // (sr_uf_dev.h uf_unite_cigar; no sr_unite_kernel launch for the batch)
+    int fuse_unite;
+    unsigned long long *uf_nodes;   // uf_rush node array
+    const uint64_t *seq_goff;       // [n] global offsets (concatenated coordinates)
+    const int32_t *max_score;       // [npairs] divergence filter bound or INT_MAX
+    uint64_t min_match_len;
     // outputs
     uint8_t *is_reverse;       // [npairs]
     int32_t *score;            // [npairs]

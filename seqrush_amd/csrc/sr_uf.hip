@@ -4,67 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include "sr_internal.h"
+#include "sr_uf_dev.h"
 #define WG SR_WG   // unite kernel workgroup size
-
-// ------------------------------------------------------------------ UF
-#define UF_PARENT_MASK 0x03FFFFFFFFFFFFFFULL
-#define UF_RANK_SHIFT 58
-
-__device__ __forceinline__ unsigned long long uf_load(unsigned long long *nodes, unsigned long long i) {
-    return __hip_atomic_load(&nodes[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ bool uf_cas(unsigned long long *nodes, unsigned long long i,
-                                       unsigned long long expect, unsigned long long desired) {
-    return __hip_atomic_compare_exchange_strong(&nodes[i], &expect, desired, __ATOMIC_RELAXED,
-                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// UFRush::find with path halving (uf_rush lib.rs:112-133)
-__device__ __forceinline__ unsigned long long uf_find(unsigned long long *nodes, unsigned long long x,
-                                                      int &err) {
-    unsigned long long x_node = uf_load(nodes, x);
-    int guard = 0;
-    while (x != (x_node & UF_PARENT_MASK)) {
-        const unsigned long long x_parent = x_node & UF_PARENT_MASK;
-        const unsigned long long x_parent_node = uf_load(nodes, x_parent);
-        const unsigned long long x_pp = x_parent_node & UF_PARENT_MASK;
-        const unsigned long long x_new = x_pp | (x_node & ~UF_PARENT_MASK);
-        if (x_new != x_node) (void)uf_cas(nodes, x, x_node, x_new);
-        x = x_pp;
-        x_node = uf_load(nodes, x);
-        if (++guard > (1 << 20)) { err |= SR_DEV_ERR_UF_SPIN; break; }
-    }
-    return x;
-}
-
-// UFRush::unite (uf_rush lib.rs:159-208)
-__device__ __forceinline__ bool uf_unite(unsigned long long *nodes, unsigned long long x,
-                                         unsigned long long y, int &err) {
-    for (int guard = 0; guard < (1 << 16); guard++) {
-        unsigned long long x_rep = uf_find(nodes, x, err);
-        unsigned long long y_rep = uf_find(nodes, y, err);
-        if (x_rep == y_rep) return false;
-        const unsigned long long x_node = uf_load(nodes, x_rep);
-        const unsigned long long y_node = uf_load(nodes, y_rep);
-        unsigned long long x_rank = x_node >> UF_RANK_SHIFT, y_rank = y_node >> UF_RANK_SHIFT;
-        if (x_rank > y_rank || (x_rank == y_rank && x_rep > y_rep)) {
-            unsigned long long tmp = x_rep; x_rep = y_rep; y_rep = tmp;
-            tmp = x_rank; x_rank = y_rank; y_rank = tmp;
-        }
-        const unsigned long long cur = x_rep | (x_rank << UF_RANK_SHIFT);
-        const unsigned long long nw = y_rep | (x_rank << UF_RANK_SHIFT);
-        if (uf_cas(nodes, x_rep, cur, nw)) {
-            if (x_rank == y_rank) {
-                const unsigned long long cv = y_rep | (y_rank << UF_RANK_SHIFT);
-                const unsigned long long nv = y_rep | ((y_rank + 1) << UF_RANK_SHIFT);
-                (void)uf_cas(nodes, y_rep, cv, nv);
-            }
-            return true;
-        }
-    }
-    err |= SR_DEV_ERR_UF_SPIN;
-    return false;
-}
 
 // SeqRush::new state (seqrush.rs:324-328): N sequential unite(2i, 2i+1) on a
 // fresh forest always ends with parent[2i] = 2i+1 (rank 0) and 2i+1 a root
@@ -83,67 +24,15 @@ __global__ void sr_uf_init_kernel(unsigned long long *nodes, unsigned long long 
 
 // process_alignment + unite_matching_region, one pair per workgroup
 __global__ void __launch_bounds__(WG) sr_unite_kernel(SrUniteArgs a) {
-    __shared__ unsigned sq[WG], st[WG], sm[WG];   // inclusive scans of one chunk
-    __shared__ unsigned long long carry_q, carry_t;
-    __shared__ unsigned wsum[3][WG / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int lane = threadIdx.x & 63;
     unsigned long long united = 0, runs = 0;
     int err = 0;
     for (uint32_t pair = blockIdx.x; pair < a.npairs; pair += gridDim.x) {
-        const uint32_t cnt = a.cigar_cnt[pair];
         if (a.score[pair] < 0 || a.score[pair] > a.max_score[pair]) continue;   // uniform
         const uint32_t q = a.pair_q[pair], t = a.pair_t[pair];
-        const unsigned long long qoff = a.seq_goff[q], toff = a.seq_goff[t];
-        const unsigned long long qlen = a.seqlen[q];
-        const bool rc = a.is_reverse[pair] != 0;
-        const uint32_t *ops = a.cigar_ops + a.cigar_base[pair];
-        if (tid == 0) { carry_q = a.q_start ? a.q_start[pair] : 0; carry_t = a.t_start ? a.t_start[pair] : 0; }
-        __syncthreads();
-        for (uint32_t base = 0; base < cnt; base += WG) {
-            const uint32_t i = base + tid;
-            unsigned dq = 0, dt = 0, ml = 0;
-            if (i < cnt) {
-                const uint32_t op = ops[i] & 15u; const unsigned len = ops[i] >> 4;
-                if (op == SR_OP_M) { dq = len; dt = len; if ((unsigned long long)len >= a.min_match_len) ml = len; }
-                else if (op == SR_OP_X) { dq = len; dt = len; }
-                else if (op == SR_OP_I) dt = len;       // raw 'I' consumes text (target)
-                else dq = len;                           // raw 'D' consumes pattern (query)
-            }
-            // block inclusive scan of (dq, dt, ml)
-            unsigned vq = dq, vt = dt, vm = ml;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const unsigned nq = __shfl_up(vq, o, 64), nt = __shfl_up(vt, o, 64), nm = __shfl_up(vm, o, 64);
-                if (lane >= o) { vq += nq; vt += nt; vm += nm; }
-            }
-            if (lane == 63) { wsum[0][wv] = vq; wsum[1][wv] = vt; wsum[2][wv] = vm; }
-            __syncthreads();
-            unsigned aq = 0, at = 0, am = 0;
-            for (int w = 0; w < wv; w++) { aq += wsum[0][w]; at += wsum[1][w]; am += wsum[2][w]; }
-            vq += aq; vt += at; vm += am;
-            sq[tid] = vq; st[tid] = vt; sm[tid] = vm;
-            __syncthreads();
-            const unsigned total_m = sm[WG - 1];
-            const unsigned long long cq = carry_q, ct = carry_t;
-            if (ml) runs++;
-            for (unsigned j = tid; j < total_m; j += WG) {
-                // op index: first idx with sm[idx] > j
-                int lo = 0, hi = WG - 1;
-                while (lo < hi) { const int mid = (lo + hi) >> 1; if (sm[mid] > j) hi = mid; else lo = mid + 1; }
-                const unsigned len = ops[base + lo] >> 4;
-                const unsigned within = j - (sm[lo] - len);
-                const unsigned long long qpos = cq + (sq[lo] - len) + within;   // query-space index
-                const unsigned long long tpos = ct + (st[lo] - len) + within;
-                unsigned long long p1, p2 = (toff + tpos) << 1;
-                if (rc) p1 = ((qoff + (qlen - 1 - qpos)) << 1) | 1ULL;
-                else p1 = (qoff + qpos) << 1;
-                if (p1 != p2) uf_unite(a.nodes, p1, p2, err);
-                united++;
-            }
-            __syncthreads();
-            if (tid == 0) { carry_q = cq + sq[WG - 1]; carry_t = ct + st[WG - 1]; }
-            __syncthreads();
-        }
+        uf_unite_cigar<WG>(a.cigar_ops + a.cigar_base[pair], a.cigar_cnt[pair], a.seq_goff[q], a.seq_goff[t], a.seqlen[q],
+                           a.is_reverse[pair] != 0, a.q_start ? a.q_start[pair] : 0, a.t_start ? a.t_start[pair] : 0,
+                           a.min_match_len, a.nodes, united, runs, err);
     }
     // counters
     for (int o = 32; o > 0; o >>= 1) {

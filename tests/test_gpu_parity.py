@@ -46,6 +46,15 @@ def run_gpu(recs, **kw):
     ctx.sync()
     cnt = ctx.counters()
     cnt["align_kernel"] = ctx.align_kernel
+    # sr_ctx_run on the same context: with the blocked kernel the workgroup that aligned a pair unites its match runs itself
+    # (round 4, "fused_unite" in the report) -- same partition as align + sr_unite_kernel above, same counters of the unite
+    ctx.reset_uf(); ctx.run(); ctx.sync()
+    labels_run = ctx.download_labels()
+    ctx.sync()
+    cnt_run = ctx.counters()
+    assert np.array_equal(labels, labels_run), "sr_ctx_run gives another partition than align + unite"
+    assert cnt_run["united_bases"] == cnt["united_bases"] and cnt_run["match_runs"] == cnt["match_runs"]
+    cnt["fused_unite"] = ctx.workspace_report().get("fused_unite")
     ctx.close()
     return ss, al, labels, nodes, cnt
 
