@@ -405,6 +405,7 @@ def main():
         # can exceed what the memory system did (C5: > 1) and is not a roofline for this kernel.
         roof = {"bound": None, "kernel": ctx.align_kernel, "achieved": rows_GBps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": rows_GBps / HBM_PEAK_GBS, "traffic": None, "kernel_ms": a_ms,
+                "kernel_ms_min_max": [min(align_ms), max(align_ms)],      # (boxes and their thermal state differ by several %)
                 "achieved_is": "row bytes counted on the device in this run (bytes.rows_counted) / kernel time (hipEvents on "
                                "the context's stream); model_frac prices SURVEY 8(d)'s ring-in-HBM model instead",
                 "model_GBps": model_GBps, "model_frac": model_GBps / HBM_PEAK_GBS,
