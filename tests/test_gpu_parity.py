@@ -207,6 +207,23 @@ def test_16bit_ring_packed_tile_indels_rc_and_ring_reuse(gpu, monkeypatch, env):
     check_parity(recs)
 
 
+@pytest.mark.parametrize("ring16", ["1", "0"])
+def test_32bit_searches_on_short_sequences(gpu, monkeypatch, ring16):
+    """SR_FORCE_INT32=1 runs the 32-bit searches -- C5's instances: the packed tile on the 16-bit ring, or (SR_RING_U16=0)
+    the 32-bit tile on int32 rows -- on inputs small enough for every pair to be compared with the oracle: ragged
+    families with indels, truncations and reverse complements, several pairs per workgroup"""
+    monkeypatch.setenv("SR_FORCE_INT32", "1")
+    monkeypatch.setenv("SR_RING_U16", ring16)
+    monkeypatch.setenv("SR_NWG", "3")
+    fam = synth.indel_family_fast(4, 1800, 0.03, 0.004, 6101, max_indel=5)
+    recs = [("a", fam[0][1]), ("b", fam[1][1][40:]), ("rc", synth.reverse_complement(fam[2][1])), ("short", fam[3][1][:333]),
+            ("tiny", b"ACGTTGCA")]
+    ss = SeqSet(recs); ctx = Context(0); ctx.load(ss, Params())
+    rep = ctx.workspace_report(); ctx.close()
+    assert rep["offset_bytes"] == 4 and rep["ring_cell_bytes"] == (2 if ring16 == "1" else 4), rep
+    check_parity(recs)
+
+
 @pytest.mark.parametrize("length", [32000, 32001])
 def test_offset_width_boundary(gpu, length):
     """longest sequence 32000 -> int16 rows, 32001 -> int32 rows (same kernel template, other instantiation);
