@@ -35,7 +35,7 @@ static const SrKnob SR_KNOBS[] = {
     {"SR_ALIGN_THREADS", "by pairs per CU", "threads per workgroup: 64 | 128 | 256 | 512 | 1024"},
     {"SR_WG_PER_CU", "4", "workgroups per CU the launch is sized for"},
     {"SR_NWG", "CUs x workgroups per CU", "cap on workgroups (several pairs per workgroup on small inputs)"},
-    {"SR_STATIC_LDS_KB", "22 / 28 / 6", "static LDS of the kernel assumed when sizing workgroups per CU (A/B builds with other tables)"},
+    {"SR_STATIC_LDS_KB", "22-32 / 28 / 6", "static LDS of the kernel assumed when sizing workgroups per CU (A/B builds with other tables)"},
     {"SR_RING_U16", "1 below 57 k", "0 = 32-bit searches keep 32-bit ring rows"},
     {"SR_LAZY_ID", "1", "0 = searches store their I/D rows from the first level (no recompute pass)"},
     {"SR_HIST_JOBS", "4", "worst-case base cases the per-workgroup history holds (1..16)"},
@@ -707,9 +707,13 @@ static int plan_kernel(sr_ctx *c, const PackedSeqs &pk, const SrPen &pen, const 
     if (impl == 2 && c->nthreads == 128 && kblock == 10 && !(bits == 2 && c->off16)) kblock = 5;   // (no 128-thread 10-level instance there)
     pl.wave_wg = impl == 2 && (c->nthreads == 64 || (c->nthreads == 128 && kblock == 10));   // lean builds: 16 / 8 pairs per CU
     if (pl.wave_wg) pl.wg_per_cu = c->nthreads == 64 ? 16 : 8;
-    size_t lds_static = (size_t)(pl.wave_wg ? 6 : impl == 2 ? 22 : 28) * 1024;      // static tables of the kernel (upper estimate)
-    if (const char *e = knob("SR_STATIC_LDS_KB")) lds_static = (size_t)std::max(1, atoi(e)) * 1024;       // (A/B builds with other table sizes)
-    const size_t lds_per_wg = c->lds_bytes + lds_static;
+    // static tables of the kernel (upper estimates; the blocked kernel's scan arrays of the fused unite grow with the
+    // workgroup: 22 520 / 25 640 / 31 880 bytes at 256 / 512 / 1024 threads)
+    auto static_lds = [&](int nthreads) -> size_t {
+        if (const char *e = knob("SR_STATIC_LDS_KB")) return (size_t)std::max(1, atoi(e)) * 1024;       // (A/B builds with other table sizes)
+        return (size_t)(pl.wave_wg ? 6 : impl != 2 ? 28 : nthreads >= 1024 ? 32 : nthreads >= 512 ? 26 : 22) * 1024;
+    };
+    const size_t lds_per_wg = c->lds_bytes + static_lds(c->nthreads);
     pl.wg_per_cu = (int)std::min<size_t>((size_t)pl.wg_per_cu, std::max<size_t>(1, (160 * 1024) / lds_per_wg));
     // long sequences: the four LDS copies leave room for two workgroups per CU (C5: 50 KB each) -- give each 8 waves, or
     // the SIMDs hold two waves (C5 subset 3 507 -> 2 200 ms).  512-thread builds: int16 rows; 32-bit searches with the
@@ -717,6 +721,7 @@ static int plan_kernel(sr_ctx *c, const PackedSeqs &pk, const SrPen &pen, const 
     const char *ru = knob("SR_RING_U16");
     const bool u16_ok = kblock == 10 && maxlen <= 57000 && !(ru && atoi(ru) == 0);
     if (impl == 2 && !pl.wave_wg && pl.wg_per_cu <= 2 && !knob("SR_ALIGN_THREADS") && (c->off16 || u16_ok)) c->nthreads = 512;
+    pl.wg_per_cu = (int)std::min<size_t>((size_t)pl.wg_per_cu, std::max<size_t>(1, (160 * 1024) / (c->lds_bytes + static_lds(c->nthreads))));
     // 32-bit searches below 57 k keep their ring as uint16 (offset + 8192): half the row bytes (C5 is bound by them).
     // The exact 10-level instance at >= 256 threads has that build; SR_RING_U16=0 keeps 32-bit rows.
     pl.ring_u16 = (impl == 2 && !c->off16 && u16_ok && c->nthreads >= 256) ? 1 : 0;
