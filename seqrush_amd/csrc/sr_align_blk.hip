@@ -101,6 +101,9 @@ extern "C" int SRK_NAME(srk_align_blk)(const SrAlignArgs *a, int nwg, size_t lds
 }
 #elif defined(SR_BLK_ONLY_PROD)   // experiment builds (seconds instead of minutes, one kernel in the disassembly): the C2 / C4 production instance only
     if (a->kblock == 10 && off16 && two && nthreads == 256 && !a->profile_ticks) return launch_blk10<int16_t, 256, true>(a, nwg, lds_bytes, st);
+#ifdef SR_NT192                   // (experiment: three-wave workgroups, five per CU)
+    if (a->kblock == 10 && off16 && two && nthreads == 192 && !a->profile_ticks) return launch_blk10<int16_t, 192, true>(a, nwg, lds_bytes, st);
+#endif
     return -1;
 }
 #else

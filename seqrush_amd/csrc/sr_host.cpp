@@ -701,7 +701,8 @@ static int plan_kernel(sr_ctx *c, const PackedSeqs &pk, const SrPen &pen, const 
     if (impl == 2 && (uint64_t)np <= (uint64_t)cus) c->nthreads = 1024;
     if (const char *e = knob("SR_ALIGN_THREADS")) {
         const int v = atoi(e);
-        if (v == 128 || v == 256 || v == 512 || (v == 1024 && impl == 2) || (v == 64 && impl == 2 && bits == 2)) c->nthreads = v;
+        if (v == 128 || v == 256 || v == 512 || (v == 1024 && impl == 2) || (v == 64 && impl == 2 && bits == 2) ||
+            (v == 192 && impl == 2 && kblock == 10 && c->off16 && bits == 2 && pen.two)) c->nthreads = v;   // (192: experiment builds only, -DSR_NT192)
     }
     if (c->nthreads == 1024 && !(impl == 2 && kblock == 10 && c->off16 && bits == 2 && pen.two)) c->nthreads = 512;   // (the one 1024-thread build)
     if (impl == 2 && c->nthreads == 128 && kblock == 10 && !(bits == 2 && c->off16)) kblock = 5;   // (no 128-thread 10-level instance there)
