@@ -36,6 +36,8 @@ import os
 import statistics
 import sys
 import time
+import glob
+import threading
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -159,6 +161,47 @@ def host_stages(recs, ctx):
         out["nodes_edges_uncompacted"] = [nn, ne]; out["nodes_edges_compacted"] = [nc, ec]
         out["gfa_bytes"] = len(gfa_c)
     return out
+
+
+class Telemetry:
+    """Shader clock and socket power of the card during the timed steps, sampled from the amdgpu hwmon files
+    (freq1_input in Hz, power1_input in uW) by a thread of this process -- context for the several per cent by which
+    boxes, and one box over a call, differ on a kernel that is bound by issue and latency rather than by HBM.  Only when
+    exactly one card exposes the files (the one-GPU box); never part of the timed work (two small sysfs reads per 5 ms)."""
+
+    def __init__(self, pci=None):
+        f = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input"))
+        if pci and len(f) > 1:                                   # several cards in sysfs: the one at the device's PCI address
+            f = [x for x in f if os.path.basename(os.path.realpath(x.split("/hwmon/")[0])).lower() == pci.lower()]
+        self.freq = f[0] if len(f) == 1 else None
+        self.why = None if self.freq else f"{len(f)} cards expose hwmon freq1_input (pci {pci})"
+        self.power = os.path.join(os.path.dirname(self.freq), "power1_input") if self.freq else None
+        self.mhz, self.watt, self._stop, self._th = [], [], threading.Event(), None
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                self.mhz.append(int(open(self.freq).read()) / 1e6)
+                self.watt.append(int(open(self.power).read()) / 1e6)
+            except Exception:
+                pass
+            self._stop.wait(0.005)
+
+    def start(self):
+        if self.freq:
+            self._th = threading.Thread(target=self._run, daemon=True)
+            self._th.start()
+
+    def stop(self):
+        if not self._th:
+            return {"unavailable": self.why}
+        self._stop.set()
+        self._th.join()
+        if not self.mhz:
+            return None
+        st = lambda v: [min(v), sum(v) / len(v), max(v)] if v else None
+        return {"sclk_mhz_min_mean_max": st(self.mhz), "power_w_min_mean_max": st(self.watt), "samples": len(self.mhz),
+                "source": os.path.dirname(self.freq)}
 
 
 def host_to_host(ss, prm, dev, config):
@@ -347,11 +390,22 @@ def main():
         step()
     fence()
     ctx.sync()
+    tel = None
+    if world == 1:
+        try:
+            pr = torch.cuda.get_device_properties(dev)
+            pci = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        except Exception:
+            pci = None
+        tel = Telemetry(pci)
+    if tel:
+        tel.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
+    telemetry = tel.stop() if tel else None
     ctx.sync()                              # raises on device fault bits
     # per-kernel durations (hipEvents on the context's stream): for the long configs the timed steps' own events
     # are read; otherwise K more untimed steps with event reads keep the timed region free of host syncs
@@ -502,6 +556,8 @@ def main():
         }
         if labels_sha:
             out["labels_sha256"] = labels_sha
+        if telemetry:
+            out["telemetry"] = telemetry
         if world == 1 and not args.no_host_stages:
             out["host_stages_ms"] = host_stages(recs, ctx)
         if world == 1 and not args.no_cpu_baseline:
