@@ -14,7 +14,8 @@ print("done, failures:", bad)
 # medium sets: lengths 800..7000, divergence 1..20 %, indels, RC: breakpoint recursion 2-5 levels deep
 import random
 bad = []
-for seed in range(60):
+MOFF = int(sys.argv[4]) if len(sys.argv) > 4 else 0          # (argv[4]: first seed of the medium sets, 60 of them)
+for seed in range(MOFF, MOFF + 60):
     rng = random.Random(5000 + seed)
     L = rng.randint(800, 7000)
     n = rng.randint(2, 3)
