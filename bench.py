@@ -181,8 +181,10 @@ class Telemetry:
     def _run(self):
         while not self._stop.is_set():
             try:
-                self.mhz.append(int(open(self.freq).read()) / 1e6)
-                self.watt.append(int(open(self.power).read()) / 1e6)
+                with open(self.freq) as fh:
+                    self.mhz.append(int(fh.read()) / 1e6)
+                with open(self.power) as fh:
+                    self.watt.append(int(fh.read()) / 1e6)
             except Exception:
                 pass
             self._stop.wait(0.005)
