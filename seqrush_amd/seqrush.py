@@ -381,7 +381,8 @@ class Context:
                     tk_p2_filter=int(out[29]), tk_p2_exact=int(out[30]), tk_p2_replay=int(out[31]),
                     st_wait_cycles=int(out[32]), st_body_cycles=int(out[33]), st_tiles=int(out[34]), st_ext_iters=int(out[35]),
                     lds_row_bytes=int(out[36]), base_requeues=int(out[37]),
-                    bounds_first=[int(out[40]), int(out[41]), int(out[42]), int(out[43])])
+                    bounds_first=[int(out[40]), int(out[41]), int(out[42]), int(out[43])],
+                    experiment=[int(out[44]), int(out[45]), int(out[46]), int(out[47])])
 
     def close(self):
         if self._h:
