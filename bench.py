@@ -26,7 +26,9 @@ roofline (dominant kernel = the alignment kernel), all per launch, everything me
                        this workload: HBM-side traffic (FETCH_SIZE x 2.00 + WRITE_SIZE x 1.00, profiles/r02_calibration.json),
                        VALU issue and wait fractions, with the kernel time, box and commit they were measured at;
                        `traffic` repeats recorded.traffic (null when nothing matches)
-  bound / bound_basis  the resource closest to its ceiling, computed from the numbers above (never a literal)
+  bound / bound_basis  the resource closest to what it can attain (hbm: traffic behind the L2 or device-counted rows against the
+                       6.3 TB/s of a streaming copy; valu-issue: against 0.39 / cycle / SIMD) when within a quarter of it, else
+                       "latency"; computed from the numbers above (never a literal)
   unite                the second kernel: united bases x 24 B (2 parent loads + 1 CAS of 8-byte nodes) / its time
 h2h_ms = SURVEY 8(d)'s `t` (host sequences -> host UF array: pack + upload + step + download), outside `value`.
 """
@@ -166,7 +168,7 @@ def host_stages(recs, ctx):
 class Telemetry:
     """Shader clock and socket power of the card during the timed steps, sampled from the amdgpu hwmon files
     (freq1_input in Hz, power1_input in uW) by a thread of this process -- context for the several per cent by which
-    boxes, and one box over a call, differ on a kernel that is bound by issue and latency rather than by HBM.  Only when
+    boxes, and one box over a call, differ on a kernel whose distance from the memory ceiling is latency (clock-bound).  Only when
     exactly one card exposes the files (the one-GPU box); never part of the timed work (two small sysfs reads per 5 ms)."""
 
     def __init__(self, pci=None):
@@ -512,36 +514,42 @@ def main():
         roof["recorded"] = rec
         if rec:
             roof["traffic"] = rec["traffic"]
-        # `bound`: whichever resource of THIS run sits closest to its ceiling.  hbm: device-counted rows / time against
-        # the 8 TB/s peak (and against the 6.3 TB/s a streaming copy sustains, MI355X_MICROARCH.md), or -- when a PMC pass of
-        # this kernel is on record -- the traffic it measured behind the L2, whichever is larger; issue: the recorded
-        # VALU-issue fraction against the 0.39 wave-instructions / cycle / SIMD four resident integer waves attain
-        # (scripts/calib) -- known only from a PMC pass, so it takes part only when `recorded` matches this
-        # kernel; a kernel near neither ceiling whose waves are parked (s_waitcnt / barriers) is "latency".
-        closeness = {"hbm": rows_GBps / HBM_PEAK_GBS}
-        basis = {"hbm_frac_of_peak": rows_GBps / HBM_PEAK_GBS, "hbm_frac_of_streaming_copy_6300": rows_GBps / 6300.0}
+        # `bound`: whichever resource of THIS run sits closest to what it can attain.  hbm: device-counted rows / time or -- when
+        # a PMC pass of this kernel is on record -- the traffic it measured behind the L2, whichever is larger, against the
+        # 6.3 TB/s a streaming copy sustains (MI355X_MICROARCH.md); issue: the recorded VALU-issue fraction against the 0.39
+        # wave-instructions / cycle / SIMD four resident integer waves attain (scripts/calib) -- known only from a
+        # PMC pass, so it takes part only when `recorded` matches this kernel; a kernel near neither is "latency".
+        # Ceilings a kernel can attain, not data-sheet peaks: 6.3 TB/s is the guide's measured streaming copy (HBM3E 8 TB/s spec),
+        # 0.39 wave-instructions / cycle / SIMD what four resident integer waves issue.  `frac` itself stays against the 8 TB/s peak.
+        HBM_ATTAINABLE_GBS = 6300.0
+        closeness = {"hbm": rows_GBps / HBM_ATTAINABLE_GBS}
+        basis = {"hbm_frac_of_peak": rows_GBps / HBM_PEAK_GBS, "hbm_frac_of_streaming_copy_6300": rows_GBps / HBM_ATTAINABLE_GBS}
         if rec and rec.get("traffic_GBps"):
             # what the memory system behind the L2 carried (DRAM-destined requests incl. Infinity-Cache hits: gfx950 has no
             # counter that separates them), from the recorded PMC pass at ITS kernel time
             basis["recorded_traffic_frac_of_peak"] = rec["traffic_GBps"] / HBM_PEAK_GBS
-            basis["recorded_traffic_frac_of_streaming_copy_6300"] = rec["traffic_GBps"] / 6300.0
-            closeness["hbm"] = max(closeness["hbm"], rec["traffic_GBps"] / HBM_PEAK_GBS)
+            basis["recorded_traffic_frac_of_streaming_copy_6300"] = rec["traffic_GBps"] / HBM_ATTAINABLE_GBS
+            closeness["hbm"] = max(closeness["hbm"], rec["traffic_GBps"] / HBM_ATTAINABLE_GBS)
         if rec and rec.get("valu_issue_frac") is not None:
             basis["valu_issue_frac_of_peak_0.5"] = rec["valu_issue_frac"]
             basis["valu_issue_frac_of_attainable_0.39"] = rec["valu_issue_frac"] * 0.5 / 0.39
             basis["wait_any_frac"] = rec.get("wait_any_frac")
             closeness["valu-issue"] = rec["valu_issue_frac"] * 0.5 / 0.39
         top = max(closeness, key=closeness.get)
-        # nothing within a quarter of its ceiling while the waves are parked in s_waitcnt / barriers for >= 45 % of their
-        # resident cycles: the kernel is bound by the latency of its dependent steps (LDS round trips of the extension, row
-        # round trips, barriers, one-wave sections), not by a throughput ceiling.  (Round-4 A/B runs agree: -8 % instructions
-        # in the tile: +-0; -9 % row bytes: +-0; -6 % tiles: -2.4 %.  DESIGN.md section 6.1.)
-        if closeness[top] < 0.75 and rec is not None and (rec.get("wait_any_frac") or 0) >= 0.45:
-            basis["note"] = ("no resource within a quarter of its ceiling and the waves parked %.0f %% of their cycles: latency of dependent "
-                             "steps; closest ceiling: %s at %.2f" % (100.0 * rec["wait_any_frac"], top, closeness[top]))
-            roof["bound"] = "latency"
-        else:
+        # The resource closest to what it can attain names the bound when it is within a quarter of it; otherwise the kernel is
+        # bound by the latency of its dependent steps.  C2 (round 4): the traffic behind the L2 runs at 0.79 of a streaming copy
+        # while the waves are parked half of their cycles -- a latency-bandwidth curve, T(pair) = F + S * (workgroups per CU) with
+        # S = the pair's bytes at ~6.5 TB/s and F = its serial critical path (more bytes cost time in
+        # proportion -- eager I/D rows +35 % bytes, +38 % -- while bytes that hit the caches, instructions and cheap tiles do not).
+        if closeness[top] >= 0.75:
             roof["bound"] = top
+            basis["note"] = ("%s at %.2f of what it can attain (hbm: 6.3 TB/s streaming copy; valu-issue: 0.39 / cycle / SIMD)%s"
+                             % (top, closeness[top], "; the waves are parked %.0f %% of their cycles: the rest of the way to the ceiling is "
+                                "latency (a pair's serial sections)" % (100.0 * rec["wait_any_frac"]) if rec and rec.get("wait_any_frac") else ""))
+        else:
+            roof["bound"] = "latency"
+            basis["note"] = ("no resource within a quarter of what it can attain (closest: %s at %.2f%s): latency of dependent steps"
+                             % (top, closeness[top], "" if rec else "; no PMC pass recorded for this workload, device-counted rows only"))
         roof["bound_basis"] = basis
         out = {
             "metric": metric, "value": total_pairs * args.steps / dt, "unit": "pairs/s",
