@@ -35,7 +35,7 @@ static const SrKnob SR_KNOBS[] = {
     {"SR_ALIGN_THREADS", "by pairs per CU", "threads per workgroup: 64 | 128 | 256 | 512 | 1024"},
     {"SR_WG_PER_CU", "4", "workgroups per CU the launch is sized for"},
     {"SR_NWG", "CUs x workgroups per CU", "cap on workgroups (several pairs per workgroup on small inputs)"},
-    {"SR_STATIC_LDS_KB", "23-32 / 28 / 6", "static LDS of the kernel assumed when sizing workgroups per CU (A/B builds with other tables)"},
+    {"SR_STATIC_LDS_KB", "23-33 / 28 / 6", "static LDS of the kernel assumed when sizing workgroups per CU (A/B builds with other tables)"},
     {"SR_RING_U16", "1 below 57 k", "0 = 32-bit searches keep 32-bit ring rows"},
     {"SR_LAZY_ID", "1", "0 = searches store their I/D rows from the first level (no recompute pass)"},
     {"SR_HIST_JOBS", "4", "worst-case base cases the per-workgroup history holds (1..16)"},
@@ -709,10 +709,10 @@ static int plan_kernel(sr_ctx *c, const PackedSeqs &pk, const SrPen &pen, const 
     pl.wave_wg = impl == 2 && (c->nthreads == 64 || (c->nthreads == 128 && kblock == 10));   // lean builds: 16 / 8 pairs per CU
     if (pl.wave_wg) pl.wg_per_cu = c->nthreads == 64 ? 16 : 8;
     // static tables of the kernel (upper estimates; the blocked kernel's scan arrays of the fused unite grow with the
-    // workgroup: 22 648 / 25 768 / 32 008 bytes at 256 / 512 / 1024 threads)
+    // workgroup: 23 416 / 26 536 / 32 776 bytes at 256 / 512 / 1024 threads)
     auto static_lds = [&](int nthreads) -> size_t {
         if (const char *e = knob("SR_STATIC_LDS_KB")) return (size_t)std::max(1, atoi(e)) * 1024;       // (A/B builds with other table sizes)
-        return (size_t)(pl.wave_wg ? 6 : impl != 2 ? 28 : nthreads >= 1024 ? 32 : nthreads >= 512 ? 26 : 23) * 1024;
+        return (size_t)(pl.wave_wg ? 6 : impl != 2 ? 28 : nthreads >= 1024 ? 33 : nthreads >= 512 ? 26 : 23) * 1024;
     };
     const size_t lds_per_wg = c->lds_bytes + static_lds(c->nthreads);
     pl.wg_per_cu = (int)std::min<size_t>((size_t)pl.wg_per_cu, std::max<size_t>(1, (160 * 1024) / lds_per_wg));
